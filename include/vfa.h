@@ -1,0 +1,142 @@
+/*
+ * vfa.h -- C ABI of the MI355X (gfx950) FlashAttention-2 library, libvfa_hip.so.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers, sizes and strides, no torch types.
+ * The PyTorch extension module `vllm_flash_attn_2_cuda` (fwd / varlen_fwd / fwd_kvcache / bwd /
+ * varlen_bwd) is a thin shim that validates tensors, allocates outputs and calls these entry
+ * points; any other host (ctypes, cgo, JNI, ...) can bind them directly.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers on the current HIP device; `stream` is a hipStream_t
+ *     (NULL = the default stream).  Calls enqueue work and return; they never synchronise and
+ *     never allocate device memory.
+ *   - strides are in ELEMENTS; the last (head_dim) stride must be 1.
+ *   - dtype: VFA_FP16 or VFA_BF16 for q/k/v/out/dout/dq/dk/dv; LSE and accumulators are fp32.
+ *   - return value: 0 on success, otherwise a negative vfa_status; vfa_last_error() returns the
+ *     message (the reference's TORCH_CHECK strings where one exists) for the calling thread.
+ */
+#ifndef VFA_H
+#define VFA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFA_FP16 0
+#define VFA_BF16 1
+
+typedef enum vfa_status {
+    VFA_OK = 0,
+    VFA_ERR_INVALID = -1,      /* failed argument check (message = the reference's check text) */
+    VFA_ERR_UNSUPPORTED = -2,  /* valid for the reference, not built here */
+    VFA_ERR_HIP = -3,          /* HIP runtime / launch error */
+    VFA_ERR_ARCH = -4          /* device is not gfx950 */
+} vfa_status;
+
+/* One argument block for every entry point (unused fields zero / NULL).
+ * Field meaning follows the reference's Flash_fwd_params / Flash_bwd_params
+ * (csrc/flash_attn/src/flash.h:24-183) as filled by set_params_fprop
+ * (csrc/flash_attn/flash_api.cpp:21-138). */
+typedef struct vfa_params {
+    int dtype;                       /* VFA_FP16 | VFA_BF16 */
+    /* q: (b, seqlen_q, h, d) or (total_q, h, d) when cu_seqlens_q is set */
+    const void *q, *k, *v;
+    void *out;                       /* same shape as q */
+    float *softmax_lse;              /* (b, h, seqlen_q) fp32; varlen: (b, h, max_seqlen_q) */
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;   /* paged: batch stride = page stride */
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    int b, seqlen_q, seqlen_k;       /* seqlen_*: max lengths (cache capacity for kv-cache) */
+    int h, h_k, d;
+    const int32_t *cu_seqlens_q;     /* (b+1) or NULL */
+    const int32_t *cu_seqlens_k;     /* (b+1), or (b) lengths when !is_seqlens_k_cumulative */
+    const int32_t *seqused_k;        /* (b) or NULL */
+    int is_seqlens_k_cumulative;
+    const int32_t *block_table;      /* (b, max_blocks) or NULL */
+    int64_t block_table_batch_stride;
+    int page_block_size;
+    const int32_t *cache_batch_idx;  /* (b) or NULL */
+    const float *alibi_slopes;       /* (h) or (b, h) fp32, or NULL */
+    int64_t alibi_slopes_batch_stride; /* 0 for (h) */
+    float p_dropout;                 /* must be 0 (dropout is compiled out of the reference fork) */
+    float softmax_scale;
+    int is_causal;
+    int window_size_left, window_size_right;   /* raw user values; folded as flash_api.cpp:289-294 */
+    /* split-KV (fwd_kvcache / decode): caller-provided fp32 scratch when num_splits > 1 */
+    int num_splits;                  /* 0/1 = no split */
+    float *softmax_lseaccum;         /* (num_splits, b, h, seqlen_q) */
+    float *oaccum;                   /* (num_splits, b, h, seqlen_q, d) */
+    /* KV-cache append: k/v new (b, seqlen_knew, h_k, d), rotary cos/sin (seqlen_ro, rotary_dim/2) */
+    const void *knew, *vnew;
+    int64_t knew_batch_stride, knew_row_stride, knew_head_stride;
+    int64_t vnew_batch_stride, vnew_row_stride, vnew_head_stride;
+    int seqlen_knew;
+    const void *rotary_cos, *rotary_sin;
+    int rotary_dim;
+    int is_rotary_interleaved;
+    /* backward */
+    const void *dout;
+    void *dq, *dk, *dv;              /* dk/dv: (b, seqlen_k, h_k, d) (summed over the GQA group) */
+    int64_t do_batch_stride, do_row_stride, do_head_stride;
+    int64_t dq_batch_stride, dq_row_stride, dq_head_stride;
+    int64_t dk_batch_stride, dk_row_stride, dk_head_stride;
+    int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
+    float *dsoftmax_sum;             /* (b, h, seqlen_q_rounded) fp32 scratch / output */
+    float *dq_accum;                 /* fp32 scratch: (b, seqlen_q_rounded, h, d_rounded), or
+                                        (total_q + 128 b, h, d_rounded) for varlen */
+    float *dk_accum, *dv_accum;      /* fp32 scratch (b, seqlen_k, h_k, d) when h != h_k, else NULL */
+    int deterministic;
+    void *stream;                    /* hipStream_t */
+} vfa_params;
+
+/* Forward, dense batch.  Replaces mha_fwd, csrc/flash_attn/flash_api.cpp:240-420
+ * (pybind name `fwd`, :941). */
+int vfa_mha_fwd(const vfa_params *p);
+
+/* Forward, ragged batch (cu_seqlens) with optional paged K/V.  Replaces mha_varlen_fwd,
+ * csrc/flash_attn/flash_api.cpp:422-669 (pybind name `varlen_fwd`, :942). */
+int vfa_mha_varlen_fwd(const vfa_params *p);
+
+/* Forward against a KV cache (decode): cache_seqlens, cache_batch_idx, paged cache, optional
+ * in-place append of knew/vnew with rotary, optional split-KV.  Replaces mha_fwd_kvcache,
+ * csrc/flash_attn/flash_api.cpp:671-937 (pybind name `fwd_kvcache`, :945). */
+int vfa_mha_fwd_kvcache(const vfa_params *p);
+
+/* Backward, dense batch.  The reference fork exports no backward (flash_api.cpp:943); the
+ * argument list is pinned by its Python call site vllm_flash_attn/flash_attn_interface.py:135-154
+ * and the parameter block csrc/flash_attn/src/flash.h:145-183. */
+int vfa_mha_bwd(const vfa_params *p);
+
+/* Backward, ragged batch.  Call site vllm_flash_attn/flash_attn_interface.py:183-207. */
+int vfa_mha_varlen_bwd(const vfa_params *p);
+
+/* Split count for the split-KV path.  Replaces num_splits_heuristic,
+ * csrc/flash_attn/flash_api.cpp:158-192. */
+int vfa_num_splits_heuristic(int batch_nheads_mblocks, int num_sms, int num_n_blocks, int max_splits);
+
+/* Split count a forward call with these dims would pick when num_splits == 0, given the device's
+ * CU count: the sizing half of set_params_splitkv, csrc/flash_attn/flash_api.cpp:194-219. */
+int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, int max_seqlen_k,
+                           int max_seqlen_q, int num_cus);
+
+/* Bytes of fp32 scratch the backward needs for dq_accum / dsoftmax_sum
+ * (csrc/flash_attn/src/flash.h:153-156,178-182). */
+size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_0);
+
+/* sizeof(vfa_params) of the built library, for foreign-function bindings to check their mirror of
+ * the struct against (no counterpart in the reference: its boundary is typed by pybind). */
+size_t vfa_params_sizeof(void);
+
+/* Message of the last failed call on this thread ("" if none). */
+const char *vfa_last_error(void);
+
+/* Library version string. */
+const char *vfa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFA_H */

@@ -1,0 +1,88 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/vfa.h
+declares; host-side helpers match the oracle; the Python package and extension import."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "vfa.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vfa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import cabi
+    lib = ctypes.CDLL(cabi.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vfa.h but not exported"
+
+
+def test_params_struct_mirror_matches():
+    import cabi
+    assert cabi.lib().vfa_params_sizeof() == ctypes.sizeof(cabi.VfaParams)
+
+
+def test_split_heuristic_matches_oracle():
+    import cabi
+    from oracle import fa_oracle
+    lib = cabi.lib()
+    for bnm in (1, 7, 48, 100, 409, 410, 900):
+        for nsm in (108, 512):
+            for nblk in (1, 3, 64, 1000):
+                assert lib.vfa_num_splits_heuristic(bnm, nsm, nblk, 128) == \
+                    fa_oracle.num_splits_heuristic(bnm, nsm, nblk, 128)
+
+
+def test_argument_checks_without_gpu():
+    """Checks that fail before any HIP call return the reference's message."""
+    import cabi
+    P = cabi.VfaParams()
+    P.dtype = 7
+    rc = cabi.lib().vfa_mha_fwd(ctypes.byref(P))
+    assert rc == -1 and b"only support fp16 and bf16" in cabi.lib().vfa_last_error()
+    P.dtype = 1
+    P.q = P.k = P.v = P.out = P.softmax_lse = 16
+    P.b, P.h, P.h_k, P.d = 1, 6, 4, 64
+    rc = cabi.lib().vfa_mha_fwd(ctypes.byref(P))
+    assert rc == -1 and b"must divide number of heads in query" in cabi.lib().vfa_last_error()
+    P.h_k = 3
+    P.p_dropout = 0.5
+    rc = cabi.lib().vfa_mha_fwd(ctypes.byref(P))
+    assert rc == -1 and b"does not support dropout" in cabi.lib().vfa_last_error()
+
+
+def test_python_package_imports_and_signatures():
+    import inspect
+    import vllm_flash_attn as fa
+    import vllm_flash_attn_2_cuda as ext
+    assert fa.__version__ == "2.5.8.post3"
+    for n in ("fwd", "varlen_fwd", "fwd_kvcache", "bwd", "varlen_bwd"):
+        assert hasattr(ext, n)
+    sig = inspect.signature(fa.flash_attn_with_kvcache)
+    assert list(sig.parameters) == ["q", "k_cache", "v_cache", "k", "v", "rotary_cos", "rotary_sin",
+                                    "cache_seqlens", "cache_batch_idx", "block_table", "softmax_scale",
+                                    "causal", "window_size", "rotary_interleaved", "alibi_slopes",
+                                    "num_splits", "out"]
+    sig = inspect.signature(fa.flash_attn_varlen_func)
+    assert list(sig.parameters) == ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q",
+                                    "max_seqlen_k", "dropout_p", "softmax_scale", "causal", "window_size",
+                                    "alibi_slopes", "deterministic", "return_attn_probs", "block_table", "out"]
+    sig = inspect.signature(fa.flash_attn_func)
+    assert list(sig.parameters) == ["q", "k", "v", "dropout_p", "softmax_scale", "causal", "window_size",
+                                    "alibi_slopes", "deterministic", "return_attn_probs", "out"]
+    from vllm_flash_attn.flash_attn_interface import _get_block_size_n  # noqa: F401
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    import torch
+    import vllm_flash_attn as fa
+    q = torch.randn(1, 4, 2, 64, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fa.flash_attn_func(q, q, q)

@@ -1,0 +1,318 @@
+"""GPU parity tests of the forward path, called through the C ABI (tests/cabi.py -> libvfa_hip.so)
+and through the Python package (vllm_flash_attn -> vllm_flash_attn_2_cuda -> C ABI).
+
+Checks: (1) the golden vectors (reference PyTorch oracle) with the reference tests' own rule
+max|out - out_ref| <= 2 * max|out_pt - out_ref| + 1e-5 (tests/test_flash_attn.py:1087);
+(2) the C oracle on seeded random inputs, to 2 ulp of the 16-bit output; (3) size-independent
+properties at BASELINE sizes."""
+import numpy as np
+import pytest
+import torch
+
+from util import bits_to_f32, expected_lse, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _cabi():
+    import cabi
+    return cabi
+
+
+def _cu(lens):
+    return torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+
+
+def _run_dense_golden(g, via):
+    from gpu_util import to_dev
+    m = g["meta"]
+    dt = m["dtype"]
+    q, k, v = (to_dev(g[x], dt) for x in "qkv")
+    slopes = torch.from_numpy(g["alibi_slopes"]).cuda() if "alibi_slopes" in g else None
+    kw = dict(causal=m["causal"], window=tuple(m["window"]), alibi_slopes=slopes)
+    if m.get("qlens"):
+        ql, kl = m["qlens"], m["klens"]
+        qu = torch.cat([q[i, :n] for i, n in enumerate(ql)])
+        ku = torch.cat([k[i, :n] for i, n in enumerate(kl)])
+        vu = torch.cat([v[i, :n] for i, n in enumerate(kl)])
+        cq, ck = _cu(ql), _cu(kl)
+        if via == "cabi":
+            out_u, lse = _cabi().fwd(qu, ku, vu, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql),
+                                     max_seqlen_k=max(kl), **kw)
+        else:
+            import vllm_flash_attn as fa
+            out_u, lse, _ = fa.flash_attn_varlen_func(qu, ku, vu, cq, ck, max(ql), max(kl), causal=m["causal"],
+                                                      window_size=tuple(m["window"]), alibi_slopes=slopes,
+                                                      return_attn_probs=True)
+        out = torch.zeros_like(q)
+        for i, n in enumerate(ql):
+            out[i, :n] = out_u[cq[i]:cq[i + 1]]
+        return out, lse
+    if via == "cabi":
+        return _cabi().fwd(q, k, v, **kw)
+    import vllm_flash_attn as fa
+    out, lse, _ = fa.flash_attn_func(q, k, v, causal=m["causal"], window_size=tuple(m["window"]),
+                                     alibi_slopes=slopes, return_attn_probs=True)
+    return out, lse
+
+
+def _check_golden(g, out, lse, mult=2.0):
+    m = g["meta"]
+    out, lse = out.float().cpu().numpy(), lse.float().cpu().numpy()
+    qlens = m.get("qlens") or [m["sq"]] * m["b"]
+    tol = mult * float(g["err_out_pt"]) + 1e-5
+    lse_ref = expected_lse(g)
+    for i, n in enumerate(qlens):
+        err = np.abs(out[i, :n] - g["out_ref"][i, :n]).max()
+        assert err <= tol, (m["name"], i, err, tol)
+        a, r = lse[i].reshape(m["h"], -1)[:, :n], lse_ref[i, :, :n]
+        assert np.array_equal(np.isposinf(a), np.isposinf(r)), m["name"]
+        fin = np.isfinite(r)
+        if fin.any():
+            assert np.abs(a[fin] - r[fin]).max() <= 2e-3 * max(1.0, np.abs(r[fin]).max()), m["name"]
+
+
+DENSE_16 = [n for n in golden_names("dense") if "fp32" not in n]
+
+
+@pytest.mark.parametrize("name", DENSE_16)
+def test_fwd_cabi_vs_golden(name):
+    g = load_golden(name)
+    out, lse = _run_dense_golden(g, "cabi")
+    _check_golden(g, out, lse)
+
+
+@pytest.mark.parametrize("name", DENSE_16)
+def test_fwd_python_api_vs_golden(name):
+    g = load_golden(name)
+    out, lse = _run_dense_golden(g, "py")
+    _check_golden(g, out, lse)
+
+
+@pytest.mark.parametrize("name", golden_names("kvcache"))
+@pytest.mark.parametrize("num_splits", [1, 3, 0])
+def test_kvcache_vs_golden(name, num_splits):
+    from gpu_util import to_dev
+    import vllm_flash_attn as fa
+    g = load_golden(name)
+    m = g["meta"]
+    dt = m["dtype"]
+    q = to_dev(g["q"], dt)
+    cs = torch.from_numpy(g["cache_seqlens"]).cuda()
+    slopes = torch.from_numpy(g["alibi_slopes"]).cuda() if "alibi_slopes" in g else None
+    if m["page"]:
+        kc, vc = to_dev(g["k_paged"], dt), to_dev(g["v_paged"], dt)
+        bt = torch.from_numpy(g["block_table"]).cuda()
+    else:
+        kc, vc, bt = to_dev(g["k"], dt), to_dev(g["v"], dt), None
+    out = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cs, block_table=bt, causal=m["causal"],
+                                     window_size=tuple(m["window"]), alibi_slopes=slopes,
+                                     num_splits=num_splits)
+    mult = 5.0 if m["alibi"] else 3.0  # tests/test_flash_attn.py:2075-2076
+    err = np.abs(out.float().cpu().numpy() - g["out_ref"]).max()
+    assert err <= mult * float(g["err_out_pt"]) + 1e-5, (name, num_splits, err)
+    # the same call through the C ABI, with the LSE
+    if num_splits >= 1:
+        out2, lse = _cabi().fwd(q, kc, vc, cache_seqlens=cs, block_table=bt, causal=m["causal"],
+                                window=tuple(m["window"]), alibi_slopes=slopes, num_splits=num_splits)
+        err2 = np.abs(out2.float().cpu().numpy() - g["out_ref"]).max()
+        assert err2 <= mult * float(g["err_out_pt"]) + 1e-5
+        lse_ref = expected_lse(g)
+        fin = np.isfinite(lse_ref)
+        assert np.abs(lse.cpu().numpy()[fin] - lse_ref[fin]).max() <= 2e-3 * max(1.0, np.abs(lse_ref[fin]).max())
+
+
+CASES = [
+    # dtype, b, sq, sk, h, hk, d, causal, window, alibi
+    ("bf16", 2, 512, 512, 4, 4, 128, True, (-1, -1), False),
+    ("bf16", 1, 1024, 1024, 2, 1, 128, False, (-1, -1), False),
+    ("fp16", 2, 300, 777, 4, 2, 64, True, (-1, -1), False),
+    ("bf16", 1, 640, 640, 4, 4, 64, True, (-1, -1), False),
+    ("fp16", 1, 257, 513, 2, 2, 128, False, (100, 20), False),
+    ("bf16", 2, 384, 384, 4, 2, 128, True, (128, 0), True),
+    ("fp16", 1, 200, 333, 3, 3, 96, True, (-1, -1), False),
+    ("bf16", 1, 130, 260, 2, 2, 256, False, (-1, -1), True),
+    ("bf16", 1, 96, 160, 2, 2, 32, True, (-1, -1), False),
+    ("fp16", 1, 16, 2000, 8, 2, 128, True, (-1, -1), False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_fwd_vs_oracle_random(case):
+    from oracle import fa_oracle
+    from gpu_util import TDT, ulp_tol
+    dt, b, sq, sk, h, hk, d, causal, window, alibi = case
+    torch.manual_seed(0)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    slopes = (torch.rand(b, h, device="cuda") * 0.3) if alibi else None
+    out, lse = _cabi().fwd(q, k, v, causal=causal, window=window, alibi_slopes=slopes)
+    ro, rl = fa_oracle.attention_fwd(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
+                                     dtype=dt, causal=causal, window=window,
+                                     alibi_slopes=None if slopes is None else slopes.cpu().numpy())
+    o = out.float().cpu().numpy()
+    assert np.abs(o - ro).max() <= ulp_tol(dt, ro)
+    l = lse.cpu().numpy()
+    assert np.array_equal(np.isposinf(l), np.isposinf(rl))
+    fin = np.isfinite(rl)
+    assert np.abs(l[fin] - rl[fin]).max() <= 1e-3
+
+
+def test_varlen_paged_vs_oracle():
+    """flash_attn_varlen_func with a paged KV cache (block_table) against the oracle."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    torch.manual_seed(1)
+    b, h, hk, d, page = 3, 4, 2, 128, 16
+    ql, kl = [70, 1, 129], [200, 333, 129]
+    nblk_seq = [(n + page - 1) // page for n in kl]
+    maxblk = max(nblk_seq)
+    nblocks = sum(nblk_seq) + 5
+    kc = torch.randn(nblocks, page, hk, d, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn(nblocks, page, hk, d, device="cuda", dtype=torch.bfloat16)
+    perm = torch.randperm(nblocks)[: b * maxblk].reshape(b, maxblk).to(torch.int32).cuda()
+    q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.bfloat16)
+    cq, ck = _cu(ql), _cu(kl)
+    out, lse = _cabi().fwd(q, kc, vc, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql),
+                           max_seqlen_k=max(kl), block_table=perm, causal=True)
+    ro, rl = fa_oracle.attention_fwd(q.float().cpu().numpy(), kc.float().cpu().numpy(), vc.float().cpu().numpy(),
+                                     dtype="bf16", causal=True, cu_seqlens_q=cq.cpu().numpy(),
+                                     cu_seqlens_k=ck.cpu().numpy(), max_seqlen_q=max(ql), max_seqlen_k=max(kl),
+                                     block_table=perm.cpu().numpy())
+    assert np.abs(out.float().cpu().numpy() - ro).max() <= ulp_tol("bf16", ro)
+    import vllm_flash_attn as fa
+    out2 = fa.flash_attn_varlen_func(q, kc, vc, cq, ck, max(ql), max(kl), causal=True, block_table=perm)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+@pytest.mark.parametrize("paged", [False, True])
+def test_kvcache_append_rotary_vs_oracle(interleaved, paged):
+    """k/v append in place + rotary on K and Q + cache_batch_idx (tests/test_flash_attn.py:1815-2076
+    exercises the same arguments; rotary has no reference-generated vector here: parity unpinned
+    beyond the oracle's restatement of rotary.h)."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(2)
+    b, sq, sk, h, hk, d, rd, snew = 3, 2, 256, 4, 2, 128, 64, 2
+    dt = torch.float16
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=dt)
+    knew = torch.randn(b, snew, hk, d, device="cuda", dtype=dt)
+    vnew = torch.randn(b, snew, hk, d, device="cuda", dtype=dt)
+    cs = torch.tensor([5, 100, 254], dtype=torch.int32, device="cuda")
+    ang = torch.rand(sk, rd // 2, device="cuda") * 6.28
+    cos, sin = torch.cos(ang).to(dt), torch.sin(ang).to(dt)
+    if paged:
+        page = 64
+        nb = b * (sk // page) + 3
+        kc = torch.randn(nb, page, hk, d, device="cuda", dtype=dt)
+        vc = torch.randn(nb, page, hk, d, device="cuda", dtype=dt)
+        bt = torch.randperm(nb)[: b * (sk // page)].reshape(b, -1).to(torch.int32).cuda()
+        cbi = None
+    else:
+        kc = torch.randn(b + 2, sk, hk, d, device="cuda", dtype=dt)
+        vc = torch.randn(b + 2, sk, hk, d, device="cuda", dtype=dt)
+        bt = None
+        cbi = torch.tensor([4, 0, 2], dtype=torch.int32, device="cuda")
+    np_ = lambda t: None if t is None else (t.float().cpu().numpy() if t.is_floating_point() else t.cpu().numpy())
+    ro, rl, rk, rv = fa_oracle.attention_fwd(np_(q), np_(kc), np_(vc), dtype="fp16", causal=True,
+                                             cache_seqlens=np_(cs), cache_batch_idx=np_(cbi), block_table=np_(bt),
+                                             knew=np_(knew), vnew=np_(vnew), rotary_cos=np_(cos), rotary_sin=np_(sin),
+                                             rotary_interleaved=interleaved)
+    out = fa.flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin, cache_seqlens=cs,
+                                     cache_batch_idx=cbi, block_table=bt, causal=True,
+                                     rotary_interleaved=interleaved)
+    assert np.array_equal(np_(vc), rv)                        # appended V: exact copy
+    assert np.abs(np_(kc) - rk).max() <= 2.0 ** -10 * 8      # rotated K: 1 ulp of fp16 at |x| < 8
+    assert np.abs(np_(out) - ro).max() <= 4 * ulp_tol("fp16", ro)
+
+
+def test_repeatable_and_batch_independent():
+    """Bitwise repeatability (tests/test_flash_attn.py:2135-2173 runs it 250x) and independence of
+    batch entries: a batch slice computed alone is bitwise equal."""
+    torch.manual_seed(3)
+    q = torch.randn(4, 1024, 8, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(4, 1024, 2, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(4, 1024, 2, 128, device="cuda", dtype=torch.bfloat16)
+    o0, l0 = _cabi().fwd(q, k, v, causal=True)
+    for _ in range(20):
+        o1, l1 = _cabi().fwd(q, k, v, causal=True)
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    o2, l2 = _cabi().fwd(q[1:2].contiguous(), k[1:2].contiguous(), v[1:2].contiguous(), causal=True)
+    assert torch.equal(o0[1:2], o2) and torch.equal(l0[1:2], l2)
+
+
+def test_strided_inputs_and_out_arg():
+    """Arbitrary batch/row/head strides with unit last stride (flash_api.cpp:58-72): packed qkv views."""
+    import vllm_flash_attn as fa
+    torch.manual_seed(4)
+    qkv = torch.randn(2, 300, 3, 4, 64, device="cuda", dtype=torch.float16)
+    ref = fa.flash_attn_func(qkv[:, :, 0].contiguous(), qkv[:, :, 1].contiguous(), qkv[:, :, 2].contiguous(), causal=True)
+    o1 = fa.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True)
+    o2 = fa.flash_attn_qkvpacked_func(qkv, causal=True)
+    buf = torch.empty_like(ref)
+    o3 = fa.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True, out=buf)
+    assert torch.equal(ref, o1) and torch.equal(ref, o2) and torch.equal(ref, o3) and o3.data_ptr() == buf.data_ptr()
+
+
+def test_headline_shape_slices_vs_oracle():
+    """BASELINE config 3 shape (b8 s4096 h32 d128 bf16 causal), reduced to b=1 (the kernel treats
+    batch entries independently, checked above): two (head) slices against the oracle."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    torch.manual_seed(0)
+    b, s, h, d = 1, 4096, 32, 128
+    q = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    out, lse = _cabi().fwd(q, k, v, causal=True)
+    for hh in (0, 31):
+        sl = lambda t: t[:, :, hh:hh + 1].float().cpu().numpy()
+        ro, rl = fa_oracle.attention_fwd(sl(q), sl(k), sl(v), dtype="bf16", causal=True)
+        assert np.abs(sl(out) - ro).max() <= ulp_tol("bf16", ro)
+        assert np.abs(lse[:, hh:hh + 1].cpu().numpy() - rl).max() <= 1e-3
+    # property: rows of softmax sum to one => with V = ones the output is exactly 1
+    ones = torch.ones_like(v)
+    o1, _ = _cabi().fwd(q, k, ones, causal=True)
+    assert torch.equal(o1, torch.ones_like(o1))
+
+
+def test_decode_config5_shape_properties():
+    """BASELINE config 5 shape per GPU shard (b128 sq1 kv8192 h32/hk8 d128 fp16), reduced batch:
+    split vs unsplit agree, GQA folding equals the unfolded call, first batch entries vs oracle."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(0)
+    b, sk, h, hk, d = 8, 8192, 32, 8, 128
+    q = torch.randn(b, 1, h, d, device="cuda", dtype=torch.float16)
+    kc = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.float16)
+    vc = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.float16)
+    cs = torch.full((b,), sk, dtype=torch.int32, device="cuda")
+    o1 = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cs, causal=True, num_splits=1)
+    o4 = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cs, causal=True, num_splits=4)
+    assert (o1.float() - o4.float()).abs().max().item() <= 2 * 2.0 ** -11
+    o_unfolded, _ = _cabi().fwd(q, kc, vc, cache_seqlens=cs, causal=True)
+    assert (o1.float() - o_unfolded.float()).abs().max().item() <= 2 * 2.0 ** -11
+    f = lambda t: t[:2].float().cpu().numpy()
+    ro, _ = fa_oracle.attention_fwd(f(q), f(kc), f(vc), dtype="fp16", cache_seqlens=cs[:2].cpu().numpy(), causal=True)
+    assert np.abs(f(o1) - ro).max() <= ulp_tol("fp16", ro)
+
+
+def test_error_messages_match_reference():
+    import vllm_flash_attn as fa
+    q = torch.randn(1, 8, 4, 64, device="cuda", dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="only support fp16 and bf16"):
+        fa.flash_attn_func(q, q, q)
+    q = q.half()
+    with pytest.raises(RuntimeError, match="does not support dropout"):
+        fa.flash_attn_func(q, q, q, dropout_p=0.1)
+    k = torch.randn(1, 8, 3, 64, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="must divide number of heads in query"):
+        fa.flash_attn_func(q, k, k)
+    kc = torch.randn(4, 24, 4, 64, device="cuda", dtype=torch.float16)
+    bt = torch.zeros(1, 2, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="divisible by 16"):
+        fa.flash_attn_with_kvcache(q, kc, kc, block_table=bt, cache_seqlens=3)

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""In-tree build of the MI355X FlashAttention library.
+
+  libvfa_hip.so                 HIP kernels + C ABI (include/vfa.h), built with hipcc for gfx950
+  vllm_flash_attn_2_cuda*.so    PyTorch extension module with the reference's pybind names
+                                (fwd / varlen_fwd / fwd_kvcache / bwd / varlen_bwd); a thin shim
+                                over the C ABI, built with g++ against the torch headers
+
+The counterpart of the reference's setup.py:134-219 (CUDAExtension "vllm_flash_attn_2_cuda").
+Usage: python build.py [--force] [--no-torch-ext]
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libvfa_hip.so")
+HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(INCLUDE, "vfa.h")]
+
+
+def build_hip(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+                if r.returncode != 0:
+                    sys.stderr.write(r.stdout + r.stderr)
+                    raise RuntimeError("hipcc failed: " + " ".join(r.args))
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in HIP_SOURCES]
+    if force or jobs or _newer(LIB, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+def torch_ext_path():
+    suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    return os.path.join(HERE, "vllm_flash_attn_2_cuda" + suffix)
+
+
+def build_torch_ext(force=False):
+    import torch
+    from torch.utils import cpp_extension
+
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    out = torch_ext_path()
+    if not (force or _newer(out, [src, LIB] + _headers())):
+        return out
+    rocm = os.environ.get("ROCM_HOME", "/opt/rocm")
+    inc = cpp_extension.include_paths()
+    cmd = ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DTORCH_EXTENSION_NAME=vllm_flash_attn_2_cuda",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           "-I", INCLUDE, "-I", os.path.join(rocm, "include"),
+           "-I", sysconfig.get_paths()["include"]]
+    for i in inc:
+        cmd += ["-isystem", i]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd += [src, "-o", out, "-L", tlib, "-L", HERE, "-L", os.path.join(rocm, "lib"),
+            "-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+            "-lamdhip64", "-lvfa_hip",
+            "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("building vllm_flash_attn_2_cuda failed")
+    return out
+
+
+def build_all(force=False, torch_ext=True):
+    lib = build_hip(force)
+    ext = build_torch_ext(force) if torch_ext else None
+    return lib, ext
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build_all(force, "--no-torch-ext" not in sys.argv))

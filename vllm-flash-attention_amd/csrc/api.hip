@@ -1,0 +1,285 @@
+// Host side of the C ABI declared in include/vfa.h: argument checks, window/causal folding,
+// kernel-parameter set-up and dispatch.  The counterpart of csrc/flash_attn/flash_api.cpp in the
+// reference, minus everything that needs torch (that part lives in torch_binding.cpp).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vfa.h"
+#include "vfa_kernel_params.h"
+
+namespace vfa {
+hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream);
+hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream);
+hipError_t run_append_kv(const KParams &p, hipStream_t stream);
+hipError_t run_bwd(const KParams &p, float *dk_accum, float *dv_accum, hipStream_t stream);
+}  // namespace vfa
+
+using vfa::KParams;
+
+static thread_local std::string g_err;
+
+#define VFA_CHECK(cond, msg)      \
+    do {                          \
+        if (!(cond)) {            \
+            g_err = (msg);        \
+            return VFA_ERR_INVALID; \
+        }                         \
+    } while (0)
+
+static int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return VFA_ERR_HIP;
+}
+
+// The reference gates on sm8x/sm90 (flash_api.cpp:254-258); here the gate is gfx950.
+static int check_arch() {
+    static thread_local int cached_dev = -1;
+    static thread_local int cached_ok = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+        cached_ok = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        cached_dev = dev;
+    }
+    if (!cached_ok) {
+        g_err = "FlashAttention (MI355X build) only supports gfx950 GPUs.";
+        return VFA_ERR_ARCH;
+    }
+    return VFA_OK;
+}
+
+static int num_cus() {
+    static thread_local int cached_dev = -1, cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        cached_dev = dev;
+    }
+    return cus;
+}
+
+// Checks shared by the three forward entry points (flash_api.cpp:262-287 and siblings).
+static int common_checks(const vfa_params *p) {
+    VFA_CHECK(p != nullptr, "null params");
+    VFA_CHECK(p->dtype == VFA_FP16 || p->dtype == VFA_BF16,
+              "FlashAttention only support fp16 and bf16 data type");
+    VFA_CHECK(p->q && p->k && p->v && p->out && p->softmax_lse, "null tensor pointer");
+    VFA_CHECK(p->b > 0, "batch size must be postive");
+    VFA_CHECK(p->d > 0 && p->d <= 256,
+              "FlashAttention forward only supports head dimension at most 256");
+    VFA_CHECK(p->d % 8 == 0, "head dimension must be a multiple of 8 (pad before calling)");
+    VFA_CHECK(p->h_k > 0 && p->h % p->h_k == 0,
+              "Number of heads in key/value must divide number of heads in query");
+    VFA_CHECK(p->p_dropout == 0.f, "This flash attention build does not support dropout.");
+    return VFA_OK;
+}
+
+// set_params_fprop (flash_api.cpp:21-138) + the folding rules in front of it (:289-294).
+static void fill_common(const vfa_params *p, KParams &k, int seqlen_q_for_fold, int seqlen_k_for_fold) {
+    std::memset(&k, 0, sizeof(k));
+    k.is_bf16 = p->dtype == VFA_BF16;
+    k.q = p->q; k.k = p->k; k.v = p->v; k.o = p->out; k.lse = p->softmax_lse;
+    k.q_bs = p->q_batch_stride; k.q_rs = p->q_row_stride; k.q_hs = p->q_head_stride;
+    k.k_bs = p->k_batch_stride; k.k_rs = p->k_row_stride; k.k_hs = p->k_head_stride;
+    k.v_bs = p->v_batch_stride; k.v_rs = p->v_row_stride; k.v_hs = p->v_head_stride;
+    k.o_bs = p->o_batch_stride; k.o_rs = p->o_row_stride; k.o_hs = p->o_head_stride;
+    k.b = p->b; k.h = p->h; k.h_k = p->h_k; k.h_ratio = p->h / p->h_k; k.d = p->d;
+    k.seqlen_q = p->seqlen_q; k.seqlen_k = p->seqlen_k;
+    k.cu_seqlens_q = p->cu_seqlens_q; k.cu_seqlens_k = p->cu_seqlens_k;
+    k.seqused_k = p->seqused_k;
+    k.k_cumulative = p->cu_seqlens_k ? p->is_seqlens_k_cumulative : 1;
+    k.block_table = p->block_table; k.bt_bs = p->block_table_batch_stride;
+    k.page_size = p->block_table ? p->page_block_size : 1;
+    k.cache_batch_idx = p->cache_batch_idx;
+    k.alibi_slopes = p->alibi_slopes; k.alibi_bs = (int)p->alibi_slopes_batch_stride;
+    k.scale = p->softmax_scale;
+    k.scale_log2 = p->softmax_scale * (float)M_LOG2E;  // flash_api.cpp:103
+
+    int wl = p->window_size_left, wr = p->window_size_right, causal = p->is_causal;
+    if (wl >= seqlen_k_for_fold) wl = -1;              // flash_api.cpp:289-290
+    if (wr >= seqlen_k_for_fold) wr = -1;
+    if (seqlen_q_for_fold == 1 && !p->alibi_slopes) causal = 0;  // :293
+    if (causal) wr = 0;                                // :294
+    k.is_causal = (wl < 0 && wr == 0);                 // :121
+    if (wl < 0 && wr >= 0) wl = seqlen_k_for_fold;     // :123-124
+    if (wl >= 0 && wr < 0) wr = seqlen_k_for_fold;
+    k.wl = wl; k.wr = wr;
+    k.is_local = (wl >= 0 || wr >= 0) && !k.is_causal;
+    k.num_splits = 1;
+}
+
+extern "C" int vfa_num_splits_heuristic(int batch_nheads_mblocks, int num_sms, int num_n_blocks,
+                                        int max_splits) {
+    // flash_api.cpp:158-192
+    if (batch_nheads_mblocks >= 0.8f * num_sms) return 1;
+    max_splits = std::min(std::min(max_splits, num_sms), num_n_blocks);
+    float max_eff = 0.f;
+    std::vector<float> eff;
+    eff.reserve(max_splits > 0 ? max_splits : 1);
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    auto eligible = [&](int s) { return s == 1 || cdiv(num_n_blocks, s) != cdiv(num_n_blocks, s - 1); };
+    for (int s = 1; s <= max_splits; s++) {
+        if (!eligible(s)) { eff.push_back(0.f); continue; }
+        float n_waves = float(batch_nheads_mblocks * s) / num_sms;
+        float e = n_waves / std::ceil(n_waves);
+        if (e > max_eff) max_eff = e;
+        eff.push_back(e);
+    }
+    for (int s = 1; s <= max_splits; s++) {
+        if (!eligible(s)) continue;
+        if (eff[s - 1] >= 0.85f * max_eff) return s;
+    }
+    return 1;
+}
+
+extern "C" int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, int max_seqlen_k,
+                                      int max_seqlen_q, int num_cus_) {
+    // flash_api.cpp:199-210.  The work items of the split kernel here are (batch, kv head,
+    // 64-row block) with 64-key tiles... the block sizes below follow the reference so that the
+    // split count (and therefore the scratch shapes callers allocate) is the same function.
+    const int block_n = head_size <= 64 ? 256 : (head_size <= 128 ? 128 : 64);
+    const int num_n_blocks = (max_seqlen_k + block_n - 1) / block_n;
+    const int num_m_blocks = (max_seqlen_q + 64 - 1) / 64;
+    return vfa_num_splits_heuristic(batch * num_heads * num_m_blocks, num_cus_ * 2, num_n_blocks, 128);
+}
+
+static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
+    hipStream_t stream = (hipStream_t)p->stream;
+    hipError_t e;
+    if (k.knew) {
+        e = vfa::run_append_kv(k, stream);
+        if (e != hipSuccess) return hip_fail(e, "append_kv launch");
+        // the cache now holds the new rows; the attention kernels read it as a longer cache
+    }
+    if (p->num_splits > 1) {
+        VFA_CHECK(p->num_splits <= 128, "num_splits > 128 not supported");
+        VFA_CHECK(p->oaccum && p->softmax_lseaccum, "split-KV needs oaccum / softmax_lseaccum scratch");
+        k.num_splits = p->num_splits;
+        k.oaccum = p->oaccum;
+        k.lseaccum = p->softmax_lseaccum;
+        e = vfa::run_fwd_splitkv(k, stream);
+        if (e != hipSuccess) return hip_fail(e, "splitkv launch");
+        return VFA_OK;
+    }
+    // Small query blocks against long keys (decode): the split kernel's tiling (few query rows,
+    // many waves along the keys) is the right one even with a single split.
+    if (force_split || k.seqlen_q <= 32) {
+        e = vfa::run_fwd_splitkv(k, stream);
+        if (e != hipSuccess) return hip_fail(e, "decode launch");
+        return VFA_OK;
+    }
+    e = vfa::run_fwd_prefill(k, stream);
+    if (e != hipSuccess) return hip_fail(e, "prefill launch");
+    return VFA_OK;
+}
+
+extern "C" int vfa_mha_fwd(const vfa_params *p) {
+    g_err.clear();
+    int rc = common_checks(p);
+    if (rc) return rc;
+    if ((rc = check_arch())) return rc;
+    VFA_CHECK(!p->cu_seqlens_q && !p->cu_seqlens_k, "vfa_mha_fwd takes dense batches");
+    VFA_CHECK(p->seqlen_q > 0, "seqlen_q must be positive");
+    KParams k;
+    fill_common(p, k, p->seqlen_q, p->seqlen_k);
+    return launch_fwd(p, k, false);
+}
+
+extern "C" int vfa_mha_varlen_fwd(const vfa_params *p) {
+    g_err.clear();
+    int rc = common_checks(p);
+    if (rc) return rc;
+    if ((rc = check_arch())) return rc;
+    // cu_seqlens_q may be NULL for a dense query batch (single-token GQA decode folded into rows,
+    // flash_api.cpp:500-507)
+    VFA_CHECK(p->cu_seqlens_k, "cu_seqlens_k is required");
+    VFA_CHECK(!p->block_table || p->page_block_size % 16 == 0,
+              "Paged KV cache block size must be divisible by 16");
+    KParams k;
+    // flash_api.cpp:493-494,515-516: the varlen entry folds with the MAX lengths
+    fill_common(p, k, p->seqlen_q, p->seqlen_k);
+    k.k_cumulative = 1;
+    return launch_fwd(p, k, false);
+}
+
+extern "C" int vfa_mha_fwd_kvcache(const vfa_params *p) {
+    g_err.clear();
+    int rc = common_checks(p);
+    if (rc) return rc;
+    if ((rc = check_arch())) return rc;
+    VFA_CHECK(!p->cu_seqlens_q, "fwd_kvcache takes a dense query batch");
+    VFA_CHECK(!(p->block_table && p->cache_batch_idx), "Paged KVcache does not support cache_batch_idx");
+    VFA_CHECK(!p->block_table || p->page_block_size % 16 == 0,
+              "Paged KV cache block size must be divisible by 16");
+    KParams k;
+    fill_common(p, k, p->seqlen_q, p->seqlen_k);
+    k.k_cumulative = p->cu_seqlens_k ? 0 : 1;  // flash_api.cpp:859-867: lengths, not offsets
+    if (p->knew) {
+        VFA_CHECK(p->vnew, "If key is supplied, value must also be passed in");
+        VFA_CHECK(p->cu_seqlens_k, "If key is supplied, seqlens_k must also be passed in");
+        VFA_CHECK(p->seqlen_q <= p->seqlen_k,
+                  "If key is supplied, it must have seqlen <= the seqlen of the KV cache");
+        k.knew = p->knew; k.vnew = p->vnew; k.seqlen_knew = p->seqlen_knew;
+        k.knew_bs = p->knew_batch_stride; k.knew_rs = p->knew_row_stride; k.knew_hs = p->knew_head_stride;
+        k.vnew_bs = p->vnew_batch_stride; k.vnew_rs = p->vnew_row_stride; k.vnew_hs = p->vnew_head_stride;
+    }
+    if (p->rotary_cos) {
+        VFA_CHECK(p->knew, "If rotary cos/sin are provided, new key / value to be appended to KV cache must also be provided");
+        VFA_CHECK(p->rotary_sin, "If rotary cos is provided, rotary sin must also be provided");
+        VFA_CHECK(p->rotary_dim <= p->d, "rotary_dim must be <= headdim");
+        VFA_CHECK(p->rotary_dim % 16 == 0, "Only rotary dimensions divisible by 16 are currently supported");
+        k.rotary_cos = p->rotary_cos; k.rotary_sin = p->rotary_sin;
+        k.rotary_dim = p->rotary_dim; k.rotary_interleaved = p->is_rotary_interleaved;
+    }
+    // flash_api.cpp:919: appending, cache_batch_idx and paged caches take the split kernel
+    const bool force = p->knew || p->cache_batch_idx || p->block_table;
+    return launch_fwd(p, k, force);
+}
+
+extern "C" size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_0) {
+    const size_t rows = total_q_or_0 > 0 ? (size_t)total_q_or_0 : (size_t)b * seqlen_q;
+    return rows * (size_t)h * (size_t)d;
+}
+
+static int bwd_common(const vfa_params *p, bool varlen) {
+    g_err.clear();
+    int rc = common_checks(p);
+    if (rc) return rc;
+    if ((rc = check_arch())) return rc;
+    VFA_CHECK(p->dout && p->dq && p->dk && p->dv, "null gradient pointer");
+    VFA_CHECK(p->dsoftmax_sum && p->dq_accum, "backward needs dsoftmax_sum / dq_accum scratch");
+    VFA_CHECK(p->h == p->h_k || (p->dk_accum && p->dv_accum),
+              "GQA/MQA backward needs dk_accum / dv_accum scratch");
+    VFA_CHECK(varlen == (p->cu_seqlens_q != nullptr), "cu_seqlens mismatch for this entry point");
+    KParams k;
+    fill_common(p, k, p->seqlen_q, p->seqlen_k);
+    k.k_cumulative = 1;
+    k.dout = p->dout; k.dq = p->dq; k.dk = p->dk; k.dv = p->dv;
+    k.do_bs = p->do_batch_stride; k.do_rs = p->do_row_stride; k.do_hs = p->do_head_stride;
+    k.dq_bs = p->dq_batch_stride; k.dq_rs = p->dq_row_stride; k.dq_hs = p->dq_head_stride;
+    k.dk_bs = p->dk_batch_stride; k.dk_rs = p->dk_row_stride; k.dk_hs = p->dk_head_stride;
+    k.dv_bs = p->dv_batch_stride; k.dv_rs = p->dv_row_stride; k.dv_hs = p->dv_head_stride;
+    k.dsoftmax_sum = p->dsoftmax_sum;
+    k.dq_accum = p->dq_accum;
+    k.deterministic = p->deterministic;
+    hipError_t e = vfa::run_bwd(k, p->dk_accum, p->dv_accum, (hipStream_t)p->stream);
+    if (e != hipSuccess) return hip_fail(e, "backward launch");
+    return VFA_OK;
+}
+
+extern "C" int vfa_mha_bwd(const vfa_params *p) { return bwd_common(p, false); }
+extern "C" int vfa_mha_varlen_bwd(const vfa_params *p) { return bwd_common(p, true); }
+
+extern "C" size_t vfa_params_sizeof(void) { return sizeof(vfa_params); }
+extern "C" const char *vfa_last_error(void) { return g_err.c_str(); }
+extern "C" const char *vfa_version(void) { return "vfa-mi355x 0.1.0 (api of vllm_flash_attn 2.5.8.post3)"; }

@@ -1,0 +1,358 @@
+// FlashAttention-2 forward ("prefill") for gfx950 / MI355X.
+//
+// Replaces compute_attn_1rowblock / flash_fwd_kernel of the reference
+// (csrc/flash_attn/src/flash_fwd_kernel.h:27-470, flash_fwd_launch_template.h:29-94).
+//
+// Structure (wave64, MFMA 32x32x16):
+//   * a workgroup of NW waves owns BM = 32*NW query rows of one (batch, head); each wave owns 32.
+//   * K/V tiles of BN = 64 keys are staged HBM -> VGPR -> LDS (double buffered, one barrier per
+//     tile); global loads of tile t+1 are issued before the MFMAs of tile t.
+//   * S^T = K Q^T ("swapped" product): the 32x32 accumulator has the query on the lane and the
+//     keys in registers, so row max / row sum are in-lane reductions plus one half-wave exchange,
+//     the running max / sum / rescale factor are one scalar per lane, and P^T (converted to
+//     16 bit) is directly the B operand of O^T += V^T P^T with no LDS round trip.
+//   * V^T fragments come from ds_read_b64_tr_b16 (hardware transpose) on the row-major V tile.
+//   * masks (causal / sliding window / key tail) and ALiBi are applied in registers, only on
+//     tiles that need them (wave-uniform test).
+#include "vfa_kernel_params.h"
+
+namespace vfa {
+
+constexpr int BN = 64;
+
+template <int DP, bool BF16, int NW>
+struct PrefillCfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int BM = NW * 32;
+    static constexpr int CPR = DP / 8;                    // 16-byte chunks per row
+    static constexpr int TILE_CHUNKS = BN * CPR;
+    static constexpr int CH = TILE_CHUNKS / NT;            // chunks per thread per tile
+    static constexpr int TILE_BYTES = BN * DP * 2;
+    static constexpr int O_ROWB = DP * 2 + 16;             // padded O staging row
+    static constexpr int KV_LDS = 4 * TILE_BYTES;          // K0 K1 V0 V1
+    static constexpr int O_LDS = NW * 32 * O_ROWB;
+    static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+    static_assert(TILE_CHUNKS % NT == 0, "tile must divide over threads");
+};
+
+template <int DP, bool BF16, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
+fwd_prefill_kernel(const KParams p, const int n_mblocks) {
+    using Cfg = PrefillCfg<DP, BF16, NW>;
+    constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
+    constexpr int KS = DP / 16;   // k-steps of QK^T
+    constexpr int NDB = DP / 32;  // 32-wide d blocks of O
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+
+    // ---- block -> (batch, head, m_block).  Blocks b and b+8 share an XCD (round-robin
+    // dispatch), so give each XCD whole (batch, kv-head) pairs: their K/V then stay in that
+    // XCD's L2 while the pair's query heads and m-blocks stream through.  Heaviest m-blocks
+    // (causal) first. ----
+    int bidb, bidh, m_block;
+    {
+        const int g = p.h_ratio;
+        const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
+        const int P = p.b * p.h_k;
+        const int L = blockIdx.x;
+        const int full = (P / 8) * 8 * W;
+        int pair, item;
+        if (L < full) {
+            const int x = L & 7, s = L >> 3;
+            pair = (s / W) * 8 + x;
+            item = s % W;
+        } else {
+            const int Lr = L - full;
+            pair = (P / 8) * 8 + Lr / W;
+            item = Lr % W;
+        }
+        bidb = pair / p.h_k;
+        const int hk = pair % p.h_k;
+        bidh = hk * g + item % g;
+        m_block = n_mblocks - 1 - item / g;
+    }
+    const int hk = bidh / p.h_ratio;
+
+    const BlockInfo bi(p, bidb);
+    const int sq = bi.sq, sk = bi.sk;
+    if (m_block * BM >= sq) return;
+
+    // ---- key tile range: flash_fwd_kernel.h:59-67 ----
+    int n_min = !p.is_local ? 0 : max(0, (m_block * BM + sk - sq - p.wl) / BN);
+    int n_max = (sk + BN - 1) / BN;
+    if (p.is_causal || p.is_local)
+        n_max = min(n_max, ((m_block + 1) * BM + sk - sq + p.wr + BN - 1) / BN);
+
+    const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) +
+                               (int64_t)bidh * p.q_hs;
+    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
+                         (int64_t)bidh * p.o_hs;
+    float *lse_g = p.lse + ((int64_t)bidb * p.h + bidh) * p.seqlen_q;
+    const int q0w = m_block * BM + wave * 32;  // first query row of this wave
+
+    if (n_max <= n_min) {
+        // No visible key for this row block: O = 0, LSE = +inf (flash_fwd_kernel.h:70-106).
+        for (int c = tid; c < BM * CPR; c += NT) {
+            const int row = m_block * BM + c / CPR, ch = c % CPR;
+            if (row < sq && ch * 8 < p.d)
+                *(i32x4 *)(og + (int64_t)row * p.o_rs + ch * 8) = i32x4{0, 0, 0, 0};
+        }
+        for (int c = tid; c < BM; c += NT)
+            if (m_block * BM + c < sq) lse_g[m_block * BM + c] = INFINITY;
+        return;
+    }
+
+    // ---- K/V addressing ----
+    const int bidb_cache = p.cache_batch_idx ? p.cache_batch_idx[bidb] : bidb;
+    const unsigned short *kg = (const unsigned short *)p.k + (int64_t)hk * p.k_hs;
+    const unsigned short *vg = (const unsigned short *)p.v + (int64_t)hk * p.v_hs;
+    const int *bt = nullptr;
+    if (p.block_table) {
+        bt = p.block_table + (int64_t)bidb * p.bt_bs;
+    } else {
+        kg += bi.k_off(p.k_bs, p.k_rs, bidb_cache);
+        vg += bi.k_off(p.v_bs, p.v_rs, bidb_cache);
+    }
+
+    i32x4 kreg[CH], vreg[CH];
+    auto load_tile = [&](int n) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + i * NT;
+            const int row = c / CPR, ch = c % CPR;
+            const int grow = n * BN + row;
+            const bool ok = grow < sk && ch * 8 < p.d;
+            int64_t ko, vo;
+            if (bt) {  // paged: csrc/flash_attn/src/utils.h:297-315
+                const int safe = ok ? grow : 0;
+                const int page = bt[safe / p.page_size];
+                const int inpage = safe % p.page_size;
+                ko = (int64_t)page * p.k_bs + (int64_t)inpage * p.k_rs;
+                vo = (int64_t)page * p.v_bs + (int64_t)inpage * p.v_rs;
+            } else {
+                ko = (int64_t)grow * p.k_rs;
+                vo = (int64_t)grow * p.v_rs;
+            }
+            kreg[i] = ok ? *(const i32x4 *)(kg + ko + ch * 8) : i32x4{0, 0, 0, 0};
+            vreg[i] = ok ? *(const i32x4 *)(vg + vo + ch * 8) : i32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *kb = smem + buf * Cfg::TILE_BYTES;
+        char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + i * NT;
+            const int row = c / CPR, ch = c % CPR;
+            const int off = lds_off<DP>(row, ch);
+            *(i32x4 *)(kb + off) = kreg[i];
+            *(i32x4 *)(vb + off) = vreg[i];
+        }
+    };
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[q0w + r][16 s + 8 hh ..] ----
+    i32x4 qf[KS];
+    {
+        const int row = q0w + r;
+        const bool rok = row < sq;
+        const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int col = 16 * s + 8 * hh;
+            qf[s] = (rok && col < p.d) ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
+        }
+    }
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[i][j] = 0.f;
+    float m_run = -INFINITY;  // running row max (raw score units), same in both lane halves
+    float l_run = 0.f;        // running row sum, PARTIAL per lane half
+
+    float alibi = 0.f;
+    const bool has_alibi = p.alibi_slopes != nullptr;
+    if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
+    const float c2 = p.scale_log2;
+
+    // per-lane address pieces for the transposed V reads
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+
+    load_tile(n_max - 1);
+    store_tile(0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int n = n_max - 1; n >= n_min; n--) {
+        const bool has_next = n > n_min;
+        if (has_next) load_tile(n - 1);
+
+        const char *kb = smem + buf * Cfg::TILE_BYTES;
+        const char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+
+        // ---- S^T = K Q^T : s[kb2][reg] = score(key = n*64 + 32 kb2 + (reg&3) + 8 (reg>>2) + 4 hh,
+        //                                      query = q0w + r) ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; kb2++) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) s[kb2][j] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const i32x4 kf = *(const i32x4 *)(kb + lds_off<DP>(32 * kb2 + r, 2 * ks + hh));
+                s[kb2] = mma32<BF16>(kf, qf[ks], s[kb2]);
+            }
+        }
+
+        // ---- masks and ALiBi, only where needed (mask.h:128-209) ----
+        const int c0 = n * BN;
+        bool need = has_alibi || (c0 + BN > sk);
+        if (p.is_causal || p.is_local) need = need || (c0 + BN > q0w + 1 + sk - sq + p.wr);
+        if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
+        if (need) {
+            const int row = q0w + r;
+            const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
+            const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; kb2++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int col = c0 + 32 * kb2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    float x = s[kb2][j];
+                    if (has_alibi)
+                        x = p.is_causal ? x + alibi * (float)col
+                                        : x - alibi * fabsf((float)(row + sk - sq - col));
+                    s[kb2][j] = (col >= lo && col < hi) ? x : -INFINITY;
+                }
+        }
+
+        // ---- online softmax (softmax.h:135-166), one query row per lane ----
+        float mx = s[0][0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
+#pragma unroll
+        for (int j = 0; j < 16; j++) mx = fmaxf(mx, s[1][j]);
+        mx = half_swap_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float m_cur = (m_new == -INFINITY) ? 0.f : m_new;
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_cur) * c2);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; i++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) o[i][j] *= alpha;
+        }
+        m_run = m_new;
+        const float mc = m_cur * c2;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; kb2++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb2][j], c2, -mc));
+                s[kb2][j] = e;
+                psum += e;
+            }
+        l_run += psum;
+
+        // ---- O^T += V^T P^T.  P fragment of k-step ks (16 keys) = regs 8(ks&1).. of s[ks>>1];
+        // element j of lane half hh is key 16 ks + 8 (j>>2) + 4 hh + (j&3). ----
+        i32x4 pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int b8 = 8 * (ks & 1);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                pf[ks][w] = pack2<BF16>(s[ks >> 1][b8 + 2 * w], s[ks >> 1][b8 + 2 * w + 1]);
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; db++) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int row0 = 16 * ks + 4 * hh + tr_q;
+                const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
+                const s16x4 v0 = lds_read_tr16(vb + lds_off<DP>(row0, ch) + 8 * (tr_p & 1));
+                const s16x4 v1 = lds_read_tr16(vb + lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1));
+                i32x4 vf;
+                const i32x2 a0 = __builtin_bit_cast(i32x2, v0), a1 = __builtin_bit_cast(i32x2, v1);
+                vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a1[0]; vf[3] = a1[1];
+                o[db] = mma32<BF16>(vf, pf[ks], o[db]);
+            }
+        }
+
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: normalise, LSE (softmax.h:168-185), store O through LDS as whole rows ----
+    const float l_tot = half_swap_sum(l_run);
+    const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
+    const float inv = bad ? 1.f : 1.f / l_tot;
+    const float lse = bad ? INFINITY : m_run * p.scale + __logf(l_tot);
+    if (hh == 0 && q0w + r < sq) lse_g[q0w + r] = lse;
+
+    // (the loop's last __syncthreads() already fenced all LDS reads of the K/V tiles)
+    char *ob = smem + wave * 32 * Cfg::O_ROWB;
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            i32x2 w;
+            w[0] = pack2<BF16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
+            w[1] = pack2<BF16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+            *(i32x2 *)(ob + r * Cfg::O_ROWB + (32 * db + 8 * g4 + 4 * hh) * 2) = w;
+        }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < (32 * CPR) / 64; i++) {
+        const int c = lane + 64 * i;
+        const int row = c / CPR, ch = c % CPR;
+        const i32x4 w = *(const i32x4 *)(ob + row * Cfg::O_ROWB + ch * 16);
+        if (q0w + row < sq && ch * 8 < p.d)
+            *(i32x4 *)(og + (int64_t)(q0w + row) * p.o_rs + ch * 8) = w;
+    }
+}
+
+template <int DP, bool BF16, int NW>
+static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
+    using Cfg = PrefillCfg<DP, BF16, NW>;
+    const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
+    const long long blocks = (long long)n_mblocks * p.b * p.h;
+    if (blocks <= 0) return hipSuccess;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p,
+                       n_mblocks);
+    return hipGetLastError();
+}
+
+// Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
+hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
+    const bool bf = p.is_bf16;
+    const bool big = p.seqlen_q > 128;  // 8 waves x 32 rows when there are enough rows
+    if (p.d <= 64) {
+        if (big) return bf ? launch_prefill<64, true, 8>(p, stream) : launch_prefill<64, false, 8>(p, stream);
+        return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
+    } else if (p.d <= 128) {
+        if (big) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
+        return bf ? launch_prefill<128, true, 4>(p, stream) : launch_prefill<128, false, 4>(p, stream);
+    } else {
+        return bf ? launch_prefill<256, true, 4>(p, stream) : launch_prefill<256, false, 4>(p, stream);
+    }
+}
+
+}  // namespace vfa

@@ -1,0 +1,494 @@
+// Decode / split-KV forward, LSE-weighted combine, and KV-cache append (+ rotary) for gfx950.
+//
+// Replaces compute_attn_1rowblock_splitkv / flash_fwd_splitkv_kernel
+// (csrc/flash_attn/src/flash_fwd_kernel.h:474-1053), combine_attn_seqk_parallel /
+// flash_fwd_splitkv_combine_kernel (:1092-1250) and the Append_KV prologue (:672-824) of the
+// reference, launched as in flash_fwd_launch_template.h:96-166.
+//
+// Decode is HBM-bound (a few query rows against a long K/V stream), so the tiling is turned
+// around relative to the prefill kernel: a workgroup of 4 waves owns ONE block of up to 32 query
+// rows and the waves split the KEYS.  Each iteration stages 128 keys of K and V (coalesced 16-byte
+// loads -> VGPR -> LDS, next tile's loads in flight during the MFMAs); wave w computes keys
+// [32 w, 32 w + 32) of the tile with the same swapped-product MFMA scheme as the prefill kernel
+// and keeps its own running (max, sum, O); the four partial states are merged through LDS at the
+// end.  With num_splits > 1 the key range is additionally cut across workgroups, each writing a
+// normalised fp32 partial O and its LSE; a second kernel merges them.
+#include "vfa_kernel_params.h"
+
+namespace vfa {
+
+constexpr int DEC_NW = 4;
+constexpr int DEC_NT = DEC_NW * 64;
+constexpr int DEC_BM = 32;
+constexpr int DEC_BN = 32 * DEC_NW;  // keys per iteration
+
+
+// Rotary embedding of one 8-element chunk [d0, d0+8) of a row: fp32 math on 16-bit inputs, result
+// rounded back (rotary.h:57-63 interleaved pairs (2i, 2i+1); :116-132 contiguous pairs
+// (i, i + rotary_dim/2)).  cosp/sinp point at the (rotary_dim/2)-wide row of the position.
+template <bool BF16>
+__device__ __forceinline__ i32x4 rotary_chunk(const unsigned short *src, int d0,
+                                              const unsigned short *cosp, const unsigned short *sinp,
+                                              int rotary_dim, bool interleaved) {
+    if (rotary_dim == 0 || d0 >= rotary_dim) return *(const i32x4 *)(src + d0);
+    const int half = rotary_dim / 2;
+    unsigned short outv[8];
+    if (interleaved) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float x0 = to_f32<BF16>(src[d0 + 2 * i]), x1 = to_f32<BF16>(src[d0 + 2 * i + 1]);
+            const float c = to_f32<BF16>(cosp[d0 / 2 + i]), s = to_f32<BF16>(sinp[d0 / 2 + i]);
+            const int pk = pack2<BF16>(x0 * c - x1 * s, x0 * s + x1 * c);
+            outv[2 * i] = (unsigned short)(pk & 0xffff);
+            outv[2 * i + 1] = (unsigned short)((unsigned)pk >> 16);
+        }
+    } else {
+        const bool left = d0 < half;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int di = d0 + i;
+            const float x = to_f32<BF16>(src[di]);
+            const float xo = to_f32<BF16>(src[left ? di + half : di - half]);
+            const int ci = left ? di : di - half;
+            const float c = to_f32<BF16>(cosp[ci]), s = to_f32<BF16>(sinp[ci]);
+            const float y = x * c + xo * (left ? -s : s);
+            outv[i] = (unsigned short)(pack2<BF16>(y, 0.f) & 0xffff);
+        }
+    }
+    i32x4 w;
+    w[0] = outv[0] | (outv[1] << 16); w[1] = outv[2] | (outv[3] << 16);
+    w[2] = outv[4] | (outv[5] << 16); w[3] = outv[6] | (outv[7] << 16);
+    return w;
+}
+
+template <int DP>
+struct DecodeCfg {
+    static constexpr int CPR = DP / 8;
+    static constexpr int TILE_CHUNKS = DEC_BN * CPR;
+    static constexpr int CH = TILE_CHUNKS / DEC_NT;
+    static constexpr int TILE_BYTES = DEC_BN * DP * 2;
+    static constexpr int KV_LDS = 2 * TILE_BYTES;
+    static constexpr int O_ROWB = DP * 4 + 16;
+    static constexpr int O_LDS = DEC_NW * DEC_BM * O_ROWB + DEC_NW * DEC_BM * 8;
+    static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+};
+
+template <int DP, bool BF16>
+__global__ void __launch_bounds__(DEC_NT, DP == 256 ? 1 : 2)
+fwd_decode_kernel(const KParams p, const int n_mblocks) {
+    using Cfg = DecodeCfg<DP>;
+    constexpr int CPR = Cfg::CPR, CH = Cfg::CH;
+    constexpr int KS = DP / 16, NDB = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+
+    // block -> (split, batch, head, m_block); consecutive blocks walk the heads of one batch so
+    // that the query heads of a KV group (same K/V bytes) are co-scheduled.
+    int L = blockIdx.x;
+    const int m_block = L % n_mblocks; L /= n_mblocks;
+    const int bidh = L % p.h; L /= p.h;
+    const int split = L % p.num_splits; L /= p.num_splits;
+    const int bidb = L;
+    const int hk = bidh / p.h_ratio;
+    const bool is_split = p.num_splits > 1;
+
+    const BlockInfo bi(p, bidb);
+    const int sq = bi.sq, sk = bi.sk;
+    if (m_block * DEC_BM >= sq) return;
+    const int q0 = m_block * DEC_BM;
+
+    // key tile range of this split (flash_fwd_kernel.h:504-512), in units of DEC_BN keys; the
+    // per-split block count comes from the capacity p.seqlen_k like the reference's.
+    const int per = (((p.seqlen_k + DEC_BN - 1) / DEC_BN) + p.num_splits - 1) / p.num_splits;
+    int n_min = split * per;
+    if (p.is_local) n_min = max(n_min, (q0 + sk - sq - p.wl) / DEC_BN);
+    int n_max = min((sk + DEC_BN - 1) / DEC_BN, (split + 1) * per);
+    if (p.is_causal || p.is_local)
+        n_max = min(n_max, (q0 + DEC_BM + sk - sq + p.wr + DEC_BN - 1) / DEC_BN);
+
+    const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) +
+                               (int64_t)bidh * p.q_hs;
+    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
+                         (int64_t)bidh * p.o_hs;
+    const int64_t acc_row0 = (((int64_t)split * p.b + bidb) * p.h + bidh) * p.seqlen_q;
+    float *lse_g = is_split ? p.lseaccum + acc_row0
+                            : p.lse + ((int64_t)bidb * p.h + bidh) * p.seqlen_q;
+    float *oacc_g = is_split ? p.oaccum + acc_row0 * p.d : nullptr;
+
+    if (n_max <= n_min) {
+        // flash_fwd_kernel.h:513-552: O = 0 and LSE = -inf (split) / +inf (final)
+        for (int c = tid; c < DEC_BM * CPR; c += DEC_NT) {
+            const int row = q0 + c / CPR, ch = c % CPR;
+            if (row < sq && ch * 8 < p.d) {
+                if (is_split) {
+                    float *dst = oacc_g + (int64_t)row * p.d + ch * 8;
+                    *(f32x4 *)dst = f32x4{0, 0, 0, 0};
+                    *(f32x4 *)(dst + 4) = f32x4{0, 0, 0, 0};
+                } else {
+                    *(i32x4 *)(og + (int64_t)row * p.o_rs + ch * 8) = i32x4{0, 0, 0, 0};
+                }
+            }
+        }
+        for (int c = tid; c < DEC_BM; c += DEC_NT)
+            if (q0 + c < sq) lse_g[q0 + c] = is_split ? -INFINITY : INFINITY;
+        return;
+    }
+
+    const int bidb_cache = p.cache_batch_idx ? p.cache_batch_idx[bidb] : bidb;
+    const unsigned short *kg = (const unsigned short *)p.k + (int64_t)hk * p.k_hs;
+    const unsigned short *vg = (const unsigned short *)p.v + (int64_t)hk * p.v_hs;
+    const int *bt = nullptr;
+    if (p.block_table) {
+        bt = p.block_table + (int64_t)bidb * p.bt_bs;
+    } else {
+        kg += bi.k_off(p.k_bs, p.k_rs, bidb_cache);
+        vg += bi.k_off(p.v_bs, p.v_rs, bidb_cache);
+    }
+
+    i32x4 kreg[CH], vreg[CH];
+    auto load_tile = [&](int n) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + i * DEC_NT;
+            const int row = c / CPR, ch = c % CPR;
+            const int grow = n * DEC_BN + row;
+            const bool ok = grow < sk && ch * 8 < p.d;
+            int64_t ko, vo;
+            if (bt) {  // csrc/flash_attn/src/utils.h:297-315
+                const int safe = ok ? grow : 0;
+                const int page = bt[safe / p.page_size];
+                const int inpage = safe % p.page_size;
+                ko = (int64_t)page * p.k_bs + (int64_t)inpage * p.k_rs;
+                vo = (int64_t)page * p.v_bs + (int64_t)inpage * p.v_rs;
+            } else {
+                ko = (int64_t)grow * p.k_rs;
+                vo = (int64_t)grow * p.v_rs;
+            }
+            kreg[i] = ok ? *(const i32x4 *)(kg + ko + ch * 8) : i32x4{0, 0, 0, 0};
+            vreg[i] = ok ? *(const i32x4 *)(vg + vo + ch * 8) : i32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int c = tid + i * DEC_NT;
+            const int row = c / CPR, ch = c % CPR;
+            const int off = lds_off<DP>(row, ch);
+            *(i32x4 *)(smem + off) = kreg[i];
+            *(i32x4 *)(smem + Cfg::TILE_BYTES + off) = vreg[i];
+        }
+    };
+
+    // Q fragments: every wave holds the same 32 query rows
+    i32x4 qf[KS];
+    {
+        const int row = q0 + r;
+        const bool rok = row < sq;
+        const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int col = 16 * s + 8 * hh;
+            qf[s] = (rok && col < p.d) ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
+        }
+        if (p.knew && p.rotary_dim > 0 && rok) {
+            // flash_fwd_kernel.h:785-824: the query is rotated with position seqlen_k_cache
+            // (+ its row index when causal or local)
+            const int pos = bi.sk_cache + ((p.is_causal || p.is_local) ? row : 0);
+            const int half = p.rotary_dim / 2;
+            const unsigned short *cosp = (const unsigned short *)p.rotary_cos + (int64_t)pos * half;
+            const unsigned short *sinp = (const unsigned short *)p.rotary_sin + (int64_t)pos * half;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const int col = 16 * s + 8 * hh;
+                if (col < p.d)
+                    qf[s] = rotary_chunk<BF16>(qr, col, cosp, sinp, p.rotary_dim, p.rotary_interleaved);
+            }
+        }
+    }
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[i][j] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    float alibi = 0.f;
+    const bool has_alibi = p.alibi_slopes != nullptr;
+    if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
+    const float c2 = p.scale_log2;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+
+    const char *kb = smem;
+    const char *vb = smem + Cfg::TILE_BYTES;
+    const int wrow = 32 * wave;  // this wave's rows of the staged tile
+
+    load_tile(n_max - 1);
+    for (int n = n_max - 1; n >= n_min; n--) {
+        store_tile();
+        __syncthreads();
+        if (n > n_min) load_tile(n - 1);
+
+        f32x16 s;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const i32x4 kf = *(const i32x4 *)(kb + lds_off<DP>(wrow + r, 2 * ks + hh));
+            s = mma32<BF16>(kf, qf[ks], s);
+        }
+
+        const int c0 = n * DEC_BN + wrow;
+        bool need = has_alibi || (c0 + 32 > sk);
+        if (p.is_causal || p.is_local) need = need || (c0 + 32 > q0 + 1 + sk - sq + p.wr);
+        if (p.is_local) need = need || (c0 < q0 + 31 + sk - sq - p.wl);
+        if (need) {
+            const int row = q0 + r;
+            const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
+            const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int col = c0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                float x = s[j];
+                if (has_alibi)
+                    x = p.is_causal ? x + alibi * (float)col
+                                    : x - alibi * fabsf((float)(row + sk - sq - col));
+                s[j] = (col >= lo && col < hi) ? x : -INFINITY;
+            }
+        }
+
+        float mx = s[0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[j]);
+        mx = half_swap_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float m_cur = (m_new == -INFINITY) ? 0.f : m_new;
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_cur) * c2);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; i++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) o[i][j] *= alpha;
+        }
+        m_run = m_new;
+        const float mc = m_cur * c2;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j], c2, -mc));
+            s[j] = e;
+            psum += e;
+        }
+        l_run += psum;
+
+        i32x4 pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                pf[ks][w] = pack2<BF16>(s[8 * ks + 2 * w], s[8 * ks + 2 * w + 1]);
+#pragma unroll
+        for (int db = 0; db < NDB; db++) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int row0 = wrow + 16 * ks + 4 * hh + tr_q;
+                const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
+                const s16x4 v0 = lds_read_tr16(vb + lds_off<DP>(row0, ch) + 8 * (tr_p & 1));
+                const s16x4 v1 = lds_read_tr16(vb + lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1));
+                i32x4 vf;
+                const i32x2 a0 = __builtin_bit_cast(i32x2, v0), a1 = __builtin_bit_cast(i32x2, v1);
+                vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a1[0]; vf[3] = a1[1];
+                o[db] = mma32<BF16>(vf, pf[ks], o[db]);
+            }
+        }
+        __syncthreads();  // everyone is done with the staged tile before it is overwritten
+    }
+
+    // ---- merge the four waves' partial states (same algebra as the split combine) ----
+    float *ml = (float *)(smem + DEC_NW * DEC_BM * Cfg::O_ROWB);  // [wave][row][2]
+    const float l_w = half_swap_sum(l_run);
+    if (hh == 0) {
+        ml[(wave * DEC_BM + r) * 2 + 0] = m_run;
+        ml[(wave * DEC_BM + r) * 2 + 1] = l_w;
+    }
+    __syncthreads();
+    float m_all = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < DEC_NW; w++) m_all = fmaxf(m_all, ml[(w * DEC_BM + r) * 2]);
+    const float m_fin = (m_all == -INFINITY) ? 0.f : m_all;
+    float l_all = 0.f;
+#pragma unroll
+    for (int w = 0; w < DEC_NW; w++)
+        l_all += ml[(w * DEC_BM + r) * 2 + 1] *
+                 __builtin_amdgcn_exp2f((ml[(w * DEC_BM + r) * 2] - m_fin) * c2);
+    const float my_scale = __builtin_amdgcn_exp2f((m_run - m_fin) * c2);
+    const bool bad = (l_all == 0.f) || (l_all != l_all);
+    const float inv = bad ? 1.f : 1.f / l_all;
+    const float f = my_scale * inv;
+    char *ob = smem + wave * DEC_BM * Cfg::O_ROWB;
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            f32x4 w4;
+#pragma unroll
+            for (int t = 0; t < 4; t++) w4[t] = o[db][4 * g4 + t] * f;
+            *(f32x4 *)(ob + r * Cfg::O_ROWB + (32 * db + 8 * g4 + 4 * hh) * 4) = w4;
+        }
+    if (wave == 0 && hh == 0 && q0 + r < sq) {
+        // softmax.h:179: LSE = max*scale + log(sum); empty -> +inf (final) / -inf (split partial)
+        lse_g[q0 + r] = bad ? (is_split ? -INFINITY : INFINITY) : m_all * p.scale + __logf(l_all);
+    }
+    __syncthreads();
+    // each thread sums 8 consecutive d of one row over the waves
+    for (int c = tid; c < DEC_BM * CPR; c += DEC_NT) {
+        const int row = c / CPR, ch = c % CPR;
+        f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < DEC_NW; w++) {
+            const char *src = smem + (w * DEC_BM + row) * Cfg::O_ROWB + ch * 32;
+            a0 += *(const f32x4 *)src;
+            a1 += *(const f32x4 *)(src + 16);
+        }
+        if (q0 + row < sq && ch * 8 < p.d) {
+            if (is_split) {
+                float *dst = oacc_g + (int64_t)(q0 + row) * p.d + ch * 8;
+                *(f32x4 *)dst = a0;
+                *(f32x4 *)(dst + 4) = a1;
+            } else {
+                i32x4 w;
+                w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
+                w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
+                *(i32x4 *)(og + (int64_t)(q0 + row) * p.o_rs + ch * 8) = w;
+            }
+        }
+    }
+}
+
+// LSE-weighted merge of the splits: combine_attn_seqk_parallel, flash_fwd_kernel.h:1092-1250.
+// One thread per (row, 8-wide d chunk); rows = b*h*seqlen_q laid out like oaccum.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+fwd_combine_kernel(const KParams p) {
+    const int cpr = p.d / 8;
+    const int64_t total_rows = (int64_t)p.b * p.h * p.seqlen_q;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_rows * cpr) return;
+    const int64_t row = idx / cpr;
+    const int ch = (int)(idx % cpr);
+    const int sqi = (int)(row % p.seqlen_q);
+    const int bh = (int)(row / p.seqlen_q);
+    const int bidb = bh / p.h, bidh = bh % p.h;
+    const BlockInfo bi(p, bidb);
+    if (sqi >= bi.sq) return;
+
+    float lmax = -INFINITY;
+    for (int s = 0; s < p.num_splits; s++) lmax = fmaxf(lmax, p.lseaccum[s * total_rows + row]);
+    if (lmax == -INFINITY) lmax = 0.f;                       // :1156
+    float lsum = 0.f;
+    for (int s = 0; s < p.num_splits; s++) lsum += expf(p.lseaccum[s * total_rows + row] - lmax);
+    const float lse = (lsum == 0.f || lsum != lsum) ? INFINITY : logf(lsum) + lmax;  // :1164
+    if (ch == 0) p.lse[row] = lse;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    for (int s = 0; s < p.num_splits; s++) {
+        const float w = expf(p.lseaccum[s * total_rows + row] - lse);   // :1172
+        const float *src = p.oaccum + (s * total_rows + row) * p.d + ch * 8;
+        a0 += *(const f32x4 *)src * w;
+        a1 += *(const f32x4 *)(src + 4) * w;
+    }
+    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
+                         (int64_t)bidh * p.o_hs + (int64_t)sqi * p.o_rs + ch * 8;
+    i32x4 w;
+    w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
+    w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
+    *(i32x4 *)og = w;
+}
+
+// Append knew/vnew to the cache at [seqlen_k_cache, seqlen_k_cache + seqlen_knew), K rotated with
+// its position (flash_fwd_kernel.h:672-782, rotary.h:19-148).  One thread per 8-wide chunk.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+append_kv_kernel(const KParams p) {
+    const int cpr = p.d / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.b * p.seqlen_knew * p.h_k * cpr;
+    if (idx >= total) return;
+    const int ch = (int)(idx % cpr);
+    int64_t t = idx / cpr;
+    const int hk = (int)(t % p.h_k); t /= p.h_k;
+    const int tok = (int)(t % p.seqlen_knew);
+    const int bidb = (int)(t / p.seqlen_knew);
+    const BlockInfo bi(p, bidb);
+    const int row = bi.sk_cache + tok;
+    if (row >= bi.sk) return;
+    const int bidb_cache = p.cache_batch_idx ? p.cache_batch_idx[bidb] : bidb;
+    int64_t ko, vo;
+    if (p.block_table) {
+        const int page = p.block_table[(int64_t)bidb * p.bt_bs + row / p.page_size];
+        const int inpage = row % p.page_size;
+        ko = (int64_t)page * p.k_bs + (int64_t)inpage * p.k_rs + (int64_t)hk * p.k_hs;
+        vo = (int64_t)page * p.v_bs + (int64_t)inpage * p.v_rs + (int64_t)hk * p.v_hs;
+    } else {
+        ko = (int64_t)bidb_cache * p.k_bs + (int64_t)row * p.k_rs + (int64_t)hk * p.k_hs;
+        vo = (int64_t)bidb_cache * p.v_bs + (int64_t)row * p.v_rs + (int64_t)hk * p.v_hs;
+    }
+    const unsigned short *ks = (const unsigned short *)p.knew + (int64_t)bidb * p.knew_bs +
+                               (int64_t)tok * p.knew_rs + (int64_t)hk * p.knew_hs;
+    const unsigned short *vs = (const unsigned short *)p.vnew + (int64_t)bidb * p.vnew_bs +
+                               (int64_t)tok * p.vnew_rs + (int64_t)hk * p.vnew_hs;
+    unsigned short *kd = (unsigned short *)p.k + ko, *vd = (unsigned short *)p.v + vo;
+    *(i32x4 *)(vd + ch * 8) = *(const i32x4 *)(vs + ch * 8);
+    const int d0 = ch * 8;
+    const int half = p.rotary_dim / 2;
+    const unsigned short *cosp = (const unsigned short *)p.rotary_cos + (int64_t)row * half;
+    const unsigned short *sinp = (const unsigned short *)p.rotary_sin + (int64_t)row * half;
+    *(i32x4 *)(kd + d0) = rotary_chunk<BF16>(ks, d0, cosp, sinp, p.rotary_dim, p.rotary_interleaved);
+}
+
+template <int DP, bool BF16>
+static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
+    using Cfg = DecodeCfg<DP>;
+    const int n_mblocks = (p.seqlen_q + DEC_BM - 1) / DEC_BM;
+    const long long blocks = (long long)n_mblocks * p.b * p.h * p.num_splits;
+    if (blocks <= 0) return hipSuccess;
+    auto kern = fwd_decode_kernel<DP, BF16>;
+    if (Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(DEC_NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (p.num_splits > 1) {
+        const long long items = (long long)p.b * p.h * p.seqlen_q * (p.d / 8);
+        const unsigned cblocks = (unsigned)((items + 255) / 256);
+        if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_kernel<true>, dim3(cblocks), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(fwd_combine_kernel<false>, dim3(cblocks), dim3(256), 0, stream, p);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream) {
+    const bool bf = p.is_bf16;
+    if (p.d <= 64) return bf ? launch_decode<64, true>(p, stream) : launch_decode<64, false>(p, stream);
+    if (p.d <= 128) return bf ? launch_decode<128, true>(p, stream) : launch_decode<128, false>(p, stream);
+    return bf ? launch_decode<256, true>(p, stream) : launch_decode<256, false>(p, stream);
+}
+
+hipError_t run_append_kv(const KParams &p, hipStream_t stream) {
+    const long long items = (long long)p.b * p.seqlen_knew * p.h_k * (p.d / 8);
+    if (items <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((items + 255) / 256);
+    if (p.is_bf16) hipLaunchKernelGGL(append_kv_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(append_kv_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace vfa
