@@ -168,7 +168,7 @@ def test_varlen_paged_vs_oracle():
     ql, kl = [70, 1, 129], [200, 333, 129]
     nblk_seq = [(n + page - 1) // page for n in kl]
     maxblk = max(nblk_seq)
-    nblocks = sum(nblk_seq) + 5
+    nblocks = b * maxblk + 5
     kc = torch.randn(nblocks, page, hk, d, device="cuda", dtype=torch.bfloat16)
     vc = torch.randn(nblocks, page, hk, d, device="cuda", dtype=torch.bfloat16)
     perm = torch.randperm(nblocks)[: b * maxblk].reshape(b, maxblk).to(torch.int32).cuda()
