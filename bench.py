@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Headline benchmark: attention forward+backward TFLOPS at BASELINE.json's headline config
+(batch 8, seqlen 4096, 32 heads, headdim 128, bf16, causal) on N MI355X GPUs.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one forward + one backward pass of the attention op over one synthetic batch
+(torch.randn inputs resident in HBM), called through the C ABI of libvfa_hip.so.  Every rank runs
+the full headline batch (weak scaling, no collective on the data path: batches are independent);
+rank 0 prints ONE JSON line.  FLOP convention: the reference's benchmarks/benchmark_flash_attention.py
+:27-30 (4*b*s^2*h*d, /2 causal; backward = 2.5x forward).
+
+Other workloads (--workload): c2 (b4 s2048 h16 d64 causal fwd), c3_fwd, c5 (kv-cache decode, GB/s).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS_BF16 = 2500.0   # MI355X dense bf16/fp16 MFMA peak (spec)
+PEAK_HBM_GBS = 8000.0       # MI355X HBM3E peak (spec)
+
+WORKLOADS = {
+    # name: (b, sq, sk, h, hk, d, dtype, causal, mode)
+    "c3": (8, 4096, 4096, 32, 32, 128, "bf16", True, "fwd_bwd"),
+    "c3_fwd": (8, 4096, 4096, 32, 32, 128, "bf16", True, "fwd"),
+    "c2": (4, 2048, 2048, 16, 16, 64, "bf16", True, "fwd"),
+    "c5": (128, 1, 8192, 32, 8, 128, "fp16", True, "decode"),
+}
+
+
+class Hip:
+    """hipEvent access through the HIP runtime already loaded by torch."""
+
+    def __init__(self):
+        self.lib = C.CDLL("libamdhip64.so.7") if not hasattr(Hip, "_l") else Hip._l
+        Hip._l = self.lib
+        self.lib.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.lib.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.hipEventSynchronize.argtypes = [C.c_void_p]
+
+    def event(self):
+        e = C.c_void_p()
+        assert self.lib.hipEventCreate(C.byref(e)) == 0
+        return e
+
+    def record(self, e, stream):
+        assert self.lib.hipEventRecord(e, C.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self.lib.hipEventSynchronize(b)
+        assert self.lib.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return ms.value
+
+
+def fwd_flops(b, sq, sk, h, d, causal):
+    f = 4.0 * b * h * sq * sk * d
+    return f / 2 if causal else f
+
+
+def build_params(cabi, q, k, v, out, lse, causal, stream, do=None, dq=None, dk=None, dv=None, sd=None,
+                 dq_acc=None):
+    P = cabi.VfaParams()
+    P.dtype = 1 if q.dtype == torch.bfloat16 else 0
+    b, sq, h, d = q.shape
+    P.q, P.k, P.v, P.out, P.softmax_lse = (t.data_ptr() for t in (q, k, v, out, lse))
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+        cabi._set4(P, name, t)
+    P.b, P.seqlen_q, P.seqlen_k, P.h, P.h_k, P.d = b, sq, k.shape[1], h, k.shape[2], d
+    P.is_seqlens_k_cumulative = 1
+    P.softmax_scale = d ** -0.5
+    P.is_causal, P.window_size_left, P.window_size_right = int(causal), -1, -1
+    P.num_splits = 1
+    P.stream = stream
+    if do is not None:
+        P.dout, P.dq, P.dk, P.dv = (t.data_ptr() for t in (do, dq, dk, dv))
+        for name, t in (("do", do), ("dq", dq), ("dk", dk), ("dv", dv)):
+            cabi._set4(P, name, t)
+        P.dsoftmax_sum, P.dq_accum = sd.data_ptr(), dq_acc.data_ptr()
+    return P
+
+
+def cpu_baseline(name, b, sq, sk, h, hk, d, dtype, causal, mode):
+    """The CPU oracle (a scalar C port of the reference algorithm, OpenMP over (batch, head)) timed
+    on a bounded sample of the same workload: batch 1 and as many heads as threads."""
+    import numpy as np
+    from oracle import fa_oracle
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = max(1, min(threads, 16))
+    hs = threads
+    rng = np.random.default_rng(0)
+    s_q = sq if mode != "decode" else 1
+    if mode == "decode":
+        bb, hq, hkv = threads, h, hk
+        q = fa_oracle.round_to(rng.standard_normal((bb, 1, hq, d), dtype=np.float32), dtype)
+        k = fa_oracle.round_to(rng.standard_normal((bb, sk, hkv, d), dtype=np.float32), dtype)
+        v = fa_oracle.round_to(rng.standard_normal((bb, sk, hkv, d), dtype=np.float32), dtype)
+        t0 = time.perf_counter()
+        fa_oracle.attention_fwd(q, k, v, dtype=dtype, causal=causal,
+                                cache_seqlens=np.full(bb, sk, np.int32))
+        dt = time.perf_counter() - t0
+        gb = 2.0 * bb * sk * hkv * d * 2 / 1e9
+        return {"value": gb / dt, "unit": "GB/s", "cores": threads, "kind": "port",
+                "sample": f"oracle fwd_kvcache, batch {bb} of {b}, full kv_len {sk}, {dt:.1f} s"}
+    q = fa_oracle.round_to(rng.standard_normal((1, s_q, hs, d), dtype=np.float32), dtype)
+    k = fa_oracle.round_to(rng.standard_normal((1, sk, hs, d), dtype=np.float32), dtype)
+    v = fa_oracle.round_to(rng.standard_normal((1, sk, hs, d), dtype=np.float32), dtype)
+    t0 = time.perf_counter()
+    out, lse = fa_oracle.attention_fwd(q, k, v, dtype=dtype, causal=causal)
+    flops = fwd_flops(1, s_q, sk, hs, d, causal)
+    if mode == "fwd_bwd":
+        do = fa_oracle.round_to(rng.standard_normal(q.shape, dtype=np.float32), dtype)
+        fa_oracle.attention_bwd(do, q, k, v, out, lse, dtype=dtype, causal=causal)
+        flops *= 3.5
+    dt = time.perf_counter() - t0
+    return {"value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"oracle {mode}, batch 1 x {hs} heads of {b} x {h} (full seqlen {sq}), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sdpa", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL; used only for the timing barrier and max-reduce
+    import cabi
+    cabi.lib()
+    hip = Hip()
+
+    b, sq, sk, h, hk, d, dtype, causal, mode = WORKLOADS[args.workload]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    if mode == "decode":
+        q = torch.randn(b, 1, h, d, device=dev, dtype=tdt)
+        kc = torch.randn(b, sk, hk, d, device=dev, dtype=tdt)
+        vc = torch.randn(b, sk, hk, d, device=dev, dtype=tdt)
+        cs = torch.full((b,), sk, dtype=torch.int32, device=dev)
+        g = h // hk
+        # single-token GQA decode: the query heads of a KV group are folded into rows, as the
+        # extension module does (flash_api.cpp:747-755)
+        qf = q.reshape(b, hk, g, d).transpose(1, 2)
+        of = torch.empty(b, hk, g, d, device=dev, dtype=tdt).transpose(1, 2)
+        lse = torch.empty(b, hk, g, device=dev, dtype=torch.float32)
+        P = build_params(cabi, qf, kc, vc, of, lse, False, stream)
+        P.cu_seqlens_k = cs.data_ptr()
+        P.is_seqlens_k_cumulative = 0
+        step = lambda: cabi.call("vfa_mha_fwd_kvcache", P)
+        work = 2.0 * b * sk * hk * d * 2  # K + V bytes streamed once
+        unit, metric = "GB/s", "kv-cache decode K+V bytes/s (b128/GPU sq1 kv8192 h32/hk8 d128 fp16)"
+        kern_name, bound, peak, scale = "fwd_decode_kernel", "hbm", PEAK_HBM_GBS, 1e9
+    else:
+        q = torch.randn(b, sq, h, d, device=dev, dtype=tdt)
+        k = torch.randn(b, sk, hk, d, device=dev, dtype=tdt)
+        v = torch.randn(b, sk, hk, d, device=dev, dtype=tdt)
+        out = torch.empty_like(q)
+        lse = torch.empty(b, h, sq, device=dev, dtype=torch.float32)
+        Pf = build_params(cabi, q, k, v, out, lse, causal, stream)
+        f_fwd = fwd_flops(b, sq, sk, h, d, causal)
+        if mode == "fwd":
+            step = lambda: cabi.call("vfa_mha_fwd", Pf)
+            work = f_fwd
+            kern_name = "fwd_prefill_kernel"
+        else:
+            do = torch.randn_like(q)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            sd = torch.empty(b, h, (sq + 127) // 128 * 128, device=dev, dtype=torch.float32)
+            dq_acc = torch.empty(q.shape, device=dev, dtype=torch.float32)
+            Pb = build_params(cabi, q, k, v, out, lse, causal, stream, do, dq, dk, dv, sd, dq_acc)
+
+            def step():
+                cabi.call("vfa_mha_fwd", Pf)
+                cabi.call("vfa_mha_bwd", Pb)
+            work = 3.5 * f_fwd
+            kern_name = "bwd_main_kernel"
+        unit = "TFLOP/s"
+        metric = ("attention fwd+bwd TFLOPS, seqlen 4096 headdim 128 bf16 causal" if args.workload == "c3"
+                  else f"attention {mode} TFLOPS ({args.workload})")
+        bound, peak, scale = "mfma", PEAK_TFLOPS_BF16, 1e12
+
+    for _ in range(W):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    value = work * K * world / elapsed / scale
+
+    # ---- dominant-kernel duration with HIP events on the launch stream (rank 0, after the timed
+    # region so that the region itself carries no instrumentation) ----
+    roof = None
+    if rank == 0:
+        n = max(5, min(K, 20))
+        durs = []
+        if mode == "fwd_bwd":
+            evs = [(C.c_void_p * 4)(*[hip.event() for _ in range(4)]) for _ in range(n)]
+            for i in range(n):
+                cabi.call("vfa_mha_fwd", Pf)
+                Pb.stage_events = C.cast(evs[i], C.c_void_p)
+                cabi.call("vfa_mha_bwd", Pb)
+            Pb.stage_events = None
+            torch.cuda.synchronize()
+            durs = [hip.elapsed_ms(C.c_void_p(e[1]), C.c_void_p(e[2])) for e in evs]
+            kwork = 2.5 * f_fwd
+            fe = [(hip.event(), hip.event()) for _ in range(n)]
+            for a, bb_ in fe:
+                hip.record(a, stream); cabi.call("vfa_mha_fwd", Pf); hip.record(bb_, stream)
+            torch.cuda.synchronize()
+            fd = sorted(hip.elapsed_ms(a, bb_) for a, bb_ in fe)
+            extra["fwd_kernel"] = {"name": "fwd_prefill_kernel", "avg_ms": sum(fd) / len(fd),
+                                   "tflops": f_fwd / (sum(fd) / len(fd)) / 1e9}
+        else:
+            fe = [(hip.event(), hip.event()) for _ in range(n)]
+            for a, bb_ in fe:
+                hip.record(a, stream); step(); hip.record(bb_, stream)
+            torch.cuda.synchronize()
+            durs = [hip.elapsed_ms(a, bb_) for a, bb_ in fe]
+            kwork = work
+        avg = sum(durs) / len(durs)
+        achieved = kwork / (avg * 1e-3) / scale
+        roof = {"bound": bound, "kernel": kern_name, "achieved": achieved, "peak": peak,
+                "unit": unit, "frac": achieved / peak, "avg_kernel_ms": avg, "traffic": None}
+
+    # ---- torch SDPA on the same GPU and inputs (rank 0) ----
+    if rank == 0 and not args.no_sdpa and mode != "decode":
+        import torch.nn.functional as F
+        qt, kt, vt = (x.transpose(1, 2).detach().requires_grad_(mode == "fwd_bwd") for x in (q, k, v))
+        gt = torch.randn_like(qt)
+
+        def sdpa_step():
+            o = F.scaled_dot_product_attention(qt, kt, vt, is_causal=causal)
+            if mode == "fwd_bwd":
+                o.backward(gt)
+                qt.grad = kt.grad = vt.grad = None
+        try:
+            for _ in range(3):
+                sdpa_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ns = max(3, min(K, 10))
+            for _ in range(ns):
+                sdpa_step()
+            torch.cuda.synchronize()
+            st = (time.perf_counter() - t1) / ns
+            extra["sdpa_gpu"] = {"tflops": work / st / 1e12, "speedup_vs_sdpa": (work * K / elapsed / 1e12) / (work / st / 1e12) / world}
+        except Exception as e:  # noqa: BLE001
+            extra["sdpa_gpu"] = {"error": str(e)[:100]}
+
+    if rank == 0:
+        line = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: b{b} sq{sq} sk{sk} h{h}/{hk} d{d} {dtype} causal={causal} {mode}",
+                       "per_gpu_batch": b, "parallelism": f"batch-sharded replicas x{world}, no collective"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, b, sq, sk, h, hk, d, dtype, causal, mode)
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,12 +84,17 @@ typedef struct vfa_params {
     int64_t dq_batch_stride, dq_row_stride, dq_head_stride;
     int64_t dk_batch_stride, dk_row_stride, dk_head_stride;
     int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
-    float *dsoftmax_sum;             /* (b, h, seqlen_q_rounded) fp32 scratch / output */
-    float *dq_accum;                 /* fp32 scratch: (b, seqlen_q_rounded, h, d_rounded), or
-                                        (total_q + 128 b, h, d_rounded) for varlen */
-    float *dk_accum, *dv_accum;      /* fp32 scratch (b, seqlen_k, h_k, d) when h != h_k, else NULL */
+    float *dsoftmax_sum;             /* (b, h, seqlen_q rounded up to 128) fp32: rowsum(dO * O) */
+    float *dq_accum;                 /* fp32 scratch shaped like q, contiguous: (b, seqlen_q, h, d) or
+                                        (total_q, h, d); need not be zeroed by the caller */
+    float *dk_accum, *dv_accum;      /* unused (dK/dV of a GQA group are summed in registers) */
     int deterministic;
     void *stream;                    /* hipStream_t */
+    /* Optional instrumentation (NULL = off): array of 4 hipEvent_t that vfa_mha_bwd /
+     * vfa_mha_varlen_bwd record on `stream` before the preprocess kernel, before the main kernel,
+     * after the main kernel and after the dq conversion kernel, so a caller can time the main
+     * kernel alone.  No counterpart in the reference. */
+    void **stage_events;
 } vfa_params;
 
 /* Forward, dense batch.  Replaces mha_fwd, csrc/flash_attn/flash_api.cpp:240-420

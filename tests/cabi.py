@@ -39,6 +39,7 @@ class VfaParams(C.Structure):
         ("dsoftmax_sum", _p), ("dq_accum", _p), ("dk_accum", _p), ("dv_accum", _p),
         ("deterministic", _int),
         ("stream", _p),
+        ("stage_events", _p),
     ]
 
 

@@ -210,6 +210,8 @@ def main():
     dense_case(ref, "bf16_d256_s64x96_causal", "bf16", 1, 64, 96, 1, 1, 256, causal=True, grads=False)
     # overflow regression inputs scaled x5 (tests/test_flash_attn.py:2183-2228)
     dense_case(ref, "fp16_d64_s17_x5_causal", "fp16", 2, 17, 17, 2, 2, 64, causal=True, scale_in=5.0)
+    dense_case(ref, "fp16_d64_s5_x5_causal", "fp16", 2, 5, 5, 2, 2, 64, causal=True, scale_in=5.0)
+    dense_case(ref, "bf16_d128_s128_x3_causal", "bf16", 1, 128, 128, 1, 1, 128, causal=True, scale_in=3.0)
     # (7) kv-cache decode: contiguous and paged
     kvcache_case(ref, "kvc_fp16_d128_gqa_sq1", "fp16", 3, 1, 300, 4, 1, 128, True, None)
     kvcache_case(ref, "kvc_bf16_d64_sq3_causal", "bf16", 2, 3, 257, 2, 2, 64, True, None)

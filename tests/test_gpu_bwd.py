@@ -1,0 +1,184 @@
+"""GPU parity tests of the backward path (C ABI and the Python autograd wrappers).
+
+Tolerances are the reference tests' own: max|dx - dx_ref| <= 2 * max|dx_pt - dx_ref| for dense
+batches (tests/test_flash_attn.py:1096-1098), 3x for ragged batches (:1402-1404), where dx_pt is
+the same-dtype PyTorch gradient stored with the fixture; plus the C oracle to a few ulp."""
+import numpy as np
+import pytest
+import torch
+
+from util import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+GRAD_CASES = [n for n in golden_names("dense") if "fp32" not in n]
+
+
+def _cu(lens):
+    return torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+
+
+def _inputs(g):
+    from gpu_util import to_dev
+    m = g["meta"]
+    q, k, v, do = (to_dev(g[x], m["dtype"]) for x in "qkvg")
+    slopes = torch.from_numpy(g["alibi_slopes"]).cuda() if "alibi_slopes" in g else None
+    return m, q, k, v, do, slopes
+
+
+@pytest.mark.parametrize("via", ["cabi", "py"])
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_bwd_vs_golden(name, via):
+    import cabi
+    import vllm_flash_attn as fa
+    g = load_golden(name)
+    if "dq_ref" not in g:
+        pytest.skip("fixture has no gradients")
+    m, q, k, v, do, slopes = _inputs(g)
+    kw = dict(causal=m["causal"], window=tuple(m["window"]), alibi_slopes=slopes)
+    if m.get("qlens"):
+        ql, kl = m["qlens"], m["klens"]
+        cat = lambda x, ls: torch.cat([x[i, :n] for i, n in enumerate(ls)])
+        qu, dou, ku, vu = cat(q, ql), cat(do, ql), cat(k, kl), cat(v, kl)
+        cq, ck = _cu(ql), _cu(kl)
+        if via == "cabi":
+            vkw = dict(cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+            out, lse = cabi.fwd(qu, ku, vu, **kw, **vkw)
+            dqu, dku, dvu, _ = cabi.bwd(dou, qu, ku, vu, out, lse, **kw, **vkw)
+        else:
+            qu, ku, vu = (x.clone().requires_grad_() for x in (qu, ku, vu))
+            out = fa.flash_attn_varlen_func(qu, ku, vu, cq, ck, max(ql), max(kl), causal=m["causal"],
+                                            window_size=tuple(m["window"]), alibi_slopes=slopes)
+            dqu, dku, dvu = torch.autograd.grad(out, (qu, ku, vu), dou)
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        for i in range(m["b"]):
+            dq[i, :ql[i]] = dqu[cq[i]:cq[i + 1]]
+            dk[i, :kl[i]] = dku[ck[i]:ck[i + 1]]
+            dv[i, :kl[i]] = dvu[ck[i]:ck[i + 1]]
+        mult = 3.0
+    else:
+        if via == "cabi":
+            out, lse = cabi.fwd(q, k, v, **kw)
+            dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, **kw)
+        else:
+            q, k, v = (x.clone().requires_grad_() for x in (q, k, v))
+            out = fa.flash_attn_func(q, k, v, causal=m["causal"], window_size=tuple(m["window"]),
+                                     alibi_slopes=slopes)
+            dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+        mult = 2.0
+    add = 1e-5
+    if "_x5_" in name or "_x3_" in name:  # overflow inputs: 5x + 1e-3 (tests/test_flash_attn.py:2220-2228)
+        mult, add = 5.0, 1e-3
+    for nm, a in (("dq", dq), ("dk", dk), ("dv", dv)):
+        ref = g[nm + "_ref"].copy()
+        if m.get("qlens"):
+            lens = m["qlens"] if nm == "dq" else m["klens"]
+            for i, n in enumerate(lens):
+                ref[i, n:] = 0
+        err = np.abs(a.float().cpu().numpy() - ref).max()
+        tol = mult * float(g["err_" + nm + "_pt"]) + add
+        assert err <= tol, (name, nm, err, tol)
+
+
+BWD_CASES = [
+    ("bf16", 2, 384, 384, 4, 4, 128, True, (-1, -1), False),
+    ("fp16", 1, 300, 555, 4, 2, 64, True, (-1, -1), False),
+    ("bf16", 1, 512, 512, 4, 1, 128, False, (-1, -1), False),
+    ("bf16", 2, 256, 256, 2, 2, 128, True, (64, 0), True),
+    ("fp16", 1, 129, 257, 2, 2, 128, False, (30, 40), False),
+    ("bf16", 1, 100, 100, 2, 2, 96, True, (-1, -1), False),
+    ("bf16", 1, 70, 130, 1, 1, 256, True, (-1, -1), False),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=[str(c) for c in BWD_CASES])
+def test_bwd_vs_oracle_random(case):
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import TDT
+    dt, b, sq, sk, h, hk, d, causal, window, alibi = case
+    torch.manual_seed(0)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    do = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    slopes = (torch.rand(b, h, device="cuda") * 0.3) if alibi else None
+    kw = dict(causal=causal, window=window)
+    out, lse = cabi.fwd(q, k, v, alibi_slopes=slopes, **kw)
+    dq, dk, dv, sd = cabi.bwd(do, q, k, v, out, lse, alibi_slopes=slopes, **kw)
+    f = lambda t: t.float().cpu().numpy()
+    rdq, rdk, rdv, rsd = fa_oracle.attention_bwd(f(do), f(q), f(k), f(v), f(out), f(lse), dtype=dt,
+                                                 alibi_slopes=None if slopes is None else f(slopes), **kw)
+    eps = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    # P and dS are rounded to 16 bit before the products in both implementations; a different fp32
+    # summation order can flip such a rounding, so the bound is a few output ulps.
+    for nm, a, r in (("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv)):
+        err = np.abs(f(a) - r).max()
+        assert err <= 4 * eps * max(1.0, np.abs(r).max()), (nm, err, np.abs(r).max())
+    assert np.abs(f(sd)[:, :, :sq] - rsd).max() <= 1e-3 * max(1.0, np.abs(rsd).max())
+
+
+def test_bwd_noncontiguous_dout_and_packed():
+    """Non-contiguous dout honoured through its strides (tests/test_flash_attn.py:2239-2283) and
+    the packed variants' backward (which cannot run in the reference: wrong gradient arity)."""
+    import vllm_flash_attn as fa
+    torch.manual_seed(1)
+    b, s, h, d = 2, 200, 4, 64
+    qkv = torch.randn(b, s, 3, h, d, device="cuda", dtype=torch.float16, requires_grad=True)
+    out = fa.flash_attn_qkvpacked_func(qkv, causal=True)
+    g_big = torch.randn(b, s, h, 2 * d, device="cuda", dtype=torch.float16)
+    g = g_big[..., :d]  # non-contiguous rows, unit last stride
+    (dqkv,) = torch.autograd.grad(out, qkv, g)
+    q, k, v = (qkv[:, :, i].detach().clone().requires_grad_() for i in range(3))
+    out2 = fa.flash_attn_func(q, k, v, causal=True)
+    dq, dk, dv = torch.autograd.grad(out2, (q, k, v), g.contiguous())
+    assert torch.equal(dqkv[:, :, 1], dk) and torch.equal(dqkv[:, :, 2], dv)
+    assert (dqkv[:, :, 0].float() - dq.float()).abs().max().item() <= 2e-3  # dq: atomic order
+    kv = torch.stack([k.detach(), v.detach()], dim=2).requires_grad_()
+    out3 = fa.flash_attn_kvpacked_func(q.detach().requires_grad_(), kv, causal=True)
+    (dkv,) = torch.autograd.grad(out3, kv, g)
+    assert torch.equal(dkv[:, :, 0], dk) and torch.equal(dkv[:, :, 1], dv)
+
+
+def test_bwd_dk_dv_repeatable_and_no_nan_on_literal_varlen():
+    """dk / dv are summed in registers in a fixed order: bitwise repeatable.  dq uses fp32 atomics:
+    equal to rounding.  Literal cu_seqlens of tests/test_flash_attn.py:2291-2316: no NaN."""
+    import cabi
+    torch.manual_seed(2)
+    for cu in ([0, 76, 110, 256], [0, 1, 2, 3]):
+        cq = torch.tensor(cu, dtype=torch.int32, device="cuda")
+        n = cu[-1]
+        q = torch.randn(n, 4, 64, device="cuda", dtype=torch.float16)
+        k = torch.randn(n, 2, 64, device="cuda", dtype=torch.float16)
+        v = torch.randn(n, 2, 64, device="cuda", dtype=torch.float16)
+        do = torch.randn_like(q)
+        mx = max(cu[i + 1] - cu[i] for i in range(len(cu) - 1))
+        kw = dict(causal=True, cu_seqlens_q=cq, cu_seqlens_k=cq, max_seqlen_q=mx, max_seqlen_k=mx)
+        out, lse = cabi.fwd(q, k, v, **kw)
+        r0 = cabi.bwd(do, q, k, v, out, lse, **kw)
+        for t in r0[:3]:
+            assert not torch.isnan(t).any()
+        for _ in range(5):
+            r1 = cabi.bwd(do, q, k, v, out, lse, **kw)
+            assert torch.equal(r0[1], r1[1]) and torch.equal(r0[2], r1[2])
+            assert (r0[0].float() - r1[0].float()).abs().max().item() <= 4e-3
+
+
+def test_bwd_overflow_inputs():
+    """Inputs scaled x5 / x3 at tiny sequence lengths (tests/test_flash_attn.py:2183-2228): gradients
+    stay finite and agree with the oracle.  The reference's own 5x-PyTorch-error rule for such
+    inputs is applied to the *_x5_* / *_x3_* golden fixtures in test_bwd_vs_golden."""
+    import cabi
+    from oracle import fa_oracle
+    f = lambda t: t.float().cpu().numpy()
+    for s in (1, 2, 5, 17, 128):
+        torch.manual_seed(0)
+        q = torch.randn(2, s, 4, 64, device="cuda", dtype=torch.float16) * 5
+        k, v = [torch.randn(2, s, 4, 64, device="cuda", dtype=torch.float16) * 3 for _ in range(2)]
+        g = torch.randn_like(q)
+        out, lse = cabi.fwd(q, k, v, causal=True)
+        dq, dk, dv, _ = cabi.bwd(g, q, k, v, out, lse, causal=True)
+        rdq, rdk, rdv, _ = fa_oracle.attention_bwd(f(g), f(q), f(k), f(v), f(out), f(lse), dtype="fp16", causal=True)
+        for a, r in ((dq, rdq), (dk, rdk), (dv, rdv)):
+            assert torch.isfinite(a).all()
+            assert np.abs(f(a) - r).max() <= 8 * 2.0 ** -11 * max(1.0, np.abs(r).max())

@@ -110,6 +110,9 @@ def test_oracle_bwd_vs_golden(name):
         out, lse = fa_oracle.attention_fwd(q, k, v, **args)
         dq, dk, dv, _ = fa_oracle.attention_bwd(do, q, k, v, out, lse, **args)
     mult = 3.0 if m.get("qlens") else 2.0  # tests/test_flash_attn.py:1096-1098, :1402-1404
+    add = 1e-4
+    if "_x5_" in name or "_x3_" in name:       # overflow inputs: 5x + 1e-3 (:2220-2228)
+        mult, add = 5.0, 1e-3
     for name_, a in (("dq", dq), ("dk", dk), ("dv", dv)):
         ref = g[name_ + "_ref"]
         if m.get("qlens"):  # padded positions of the reference are zero-gradient
@@ -118,7 +121,7 @@ def test_oracle_bwd_vs_golden(name):
                 ref = ref.copy()
                 ref[i, n:] = 0
         err = np.abs(a - ref).max()
-        tol = mult * float(g["err_" + name_ + "_pt"]) + 1e-4
+        tol = mult * float(g["err_" + name_ + "_pt"]) + add
         assert err <= tol, (name, name_, err, tol)
 
 

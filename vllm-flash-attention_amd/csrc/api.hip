@@ -16,7 +16,7 @@ namespace vfa {
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream);
 hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream);
 hipError_t run_append_kv(const KParams &p, hipStream_t stream);
-hipError_t run_bwd(const KParams &p, float *dk_accum, float *dv_accum, hipStream_t stream);
+hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
 }  // namespace vfa
 
 using vfa::KParams;
@@ -258,8 +258,6 @@ static int bwd_common(const vfa_params *p, bool varlen) {
     if ((rc = check_arch())) return rc;
     VFA_CHECK(p->dout && p->dq && p->dk && p->dv, "null gradient pointer");
     VFA_CHECK(p->dsoftmax_sum && p->dq_accum, "backward needs dsoftmax_sum / dq_accum scratch");
-    VFA_CHECK(p->h == p->h_k || (p->dk_accum && p->dv_accum),
-              "GQA/MQA backward needs dk_accum / dv_accum scratch");
     VFA_CHECK(varlen == (p->cu_seqlens_q != nullptr), "cu_seqlens mismatch for this entry point");
     KParams k;
     fill_common(p, k, p->seqlen_q, p->seqlen_k);
@@ -272,7 +270,8 @@ static int bwd_common(const vfa_params *p, bool varlen) {
     k.dsoftmax_sum = p->dsoftmax_sum;
     k.dq_accum = p->dq_accum;
     k.deterministic = p->deterministic;
-    hipError_t e = vfa::run_bwd(k, p->dk_accum, p->dv_accum, (hipStream_t)p->stream);
+    k.seqlen_q_rounded = (p->seqlen_q + 127) / 128 * 128;
+    hipError_t e = vfa::run_bwd(k, (hipStream_t)p->stream, (hipEvent_t *)p->stage_events);
     if (e != hipSuccess) return hip_fail(e, "backward launch");
     return VFA_OK;
 }
