@@ -7,17 +7,22 @@
 //   P = exp2(S*scale_log2 - LSE*log2e),  dV = P16^T dO,  dP = dO V^T,  delta = rowsum(dO * O),
 //   dS = P * (dP - delta),  dK = scale * dS16^T Q,  dQ = scale * dS16 K.
 //
-// Three kernels:
-//   bwd_preprocess : delta (the softmax_d output), one wave per query row group
-//   bwd_main       : one workgroup (4 waves) per 128-key block of one (batch, KV head); each wave
-//                    owns 32 keys and keeps their dK^T / dV^T in accumulator registers while the
-//                    workgroup sweeps the query heads of the GQA group x 32-row query slices, so
-//                    dK / dV need no reduction across workgroups.  S and dP are computed with the
-//                    KEY on the MFMA lane, so P and dS are already B operands of the dV^T / dK^T
-//                    products; only dS crosses LDS (transposed) for dQ, which each wave computes
-//                    for one 32-wide d slice over all 128 keys and adds to the fp32 dq_accum with
-//                    float atomics (128 contiguous bytes per row segment).
-//   bwd_convert_dq : dq = round16(scale * dq_accum)
+// Three kernels, no atomics (dq, dk, dv are bitwise reproducible):
+//   bwd_preprocess : delta (the softmax_d output), one 16-lane group per query row
+//   bwd_dkdv       : KEY-stationary.  One workgroup (4 waves) per 128-key block of one (batch, KV
+//                    head); each wave owns 32 keys, holds their K / V MFMA fragments and the
+//                    dK^T / dV^T accumulators in registers, and the workgroup sweeps the query heads
+//                    of the GQA group x 32-row query slices (staged through LDS), so dK / dV need no
+//                    reduction across workgroups.  S and dP are computed with the key on the MFMA
+//                    lane, so P and dS are directly the B operands of dV^T += dO^T P and
+//                    dK^T += Q^T dS (A operands by transposed LDS reads of the slice).
+//   bwd_dq         : QUERY-stationary, the forward kernel's structure: a wave owns 32 query rows
+//                    (Q^T and dO^T fragments in registers, LSE and delta one scalar per lane), K/V
+//                    tiles of 64 keys stream through LDS; S^T = K Q^T and dP^T = V dO^T put the
+//                    query on the lane, dS^T is then the B operand of dQ^T += K^T dS^T (K^T by
+//                    transposed reads).  Recomputing S and dP here costs 2 extra products (7 instead
+//                    of 5) and removes the fp32 dQ atomics, which on this chip run at ~1.3 TB/s and
+//                    were the bound of a one-kernel design.
 #include "vfa_kernel_params.h"
 
 namespace vfa {
@@ -30,8 +35,7 @@ constexpr int BW_QM = 32;          // query rows per step
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 bwd_preprocess_kernel(const KParams p) {
-    // one 16-lane group per query row: delta = sum_d dO * O (fp32); also clears the row's fp32 dQ
-    // accumulator so that callers need not pre-zero the scratch
+    // one 16-lane group per query row: delta = sum_d dO * O (fp32)
     const int lane16 = threadIdx.x & 15;
     const int64_t row_id = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t total = (int64_t)p.b * p.h * p.seqlen_q;
@@ -46,11 +50,7 @@ bwd_preprocess_kernel(const KParams p) {
                                   (int64_t)sqi * p.o_rs + (int64_t)bidh * p.o_hs;
         const unsigned short *g = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) +
                                   (int64_t)sqi * p.do_rs + (int64_t)bidh * p.do_hs;
-        const int64_t row_base = bi.sum_s_q < 0 ? (int64_t)bidb * p.seqlen_q : (int64_t)bi.sum_s_q;
-        float *dqa = p.dq_accum + ((row_base + sqi) * p.h + bidh) * (int64_t)p.d;
         for (int c = lane16 * 8; c < p.d; c += 128) {
-            *(f32x4 *)(dqa + c) = f32x4{0, 0, 0, 0};
-            *(f32x4 *)(dqa + c + 4) = f32x4{0, 0, 0, 0};
             const i32x4 a = *(const i32x4 *)(o + c), b = *(const i32x4 *)(g + c);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -70,13 +70,11 @@ struct BwdCfg {
     static constexpr int KV_BYTES = BW_KB * DP * 2;          // one of K / V
     static constexpr int QT_BYTES = BW_QM * DP * 2;          // one of Q / dO slice
     static constexpr int QBUF_BYTES = 2 * QT_BYTES + 256;    // Q, dO, lse[32], delta[32]
-    static constexpr int DS_BYTES = BW_KB * 64;              // dS^T image [key][32 q] 16-bit
     static constexpr int OFF_K = 0;
     static constexpr int OFF_V = KV_BYTES;
     static constexpr int OFF_Q = KV_BYTES;                   // two Q buffers; they reuse the V tile's
                                                              // space once V is in registers
-    static constexpr int OFF_DS = OFF_Q + (2 * QBUF_BYTES > KV_BYTES ? 2 * QBUF_BYTES : KV_BYTES);
-    static constexpr int MAIN_LDS = OFF_DS + DS_BYTES;
+    static constexpr int MAIN_LDS = OFF_Q + (2 * QBUF_BYTES > KV_BYTES ? 2 * QBUF_BYTES : KV_BYTES);
     static constexpr int OUT_ROWB = DP * 2 + 16;
     static constexpr int OUT_LDS = BW_NW * 32 * OUT_ROWB;
     static constexpr int LDS_BYTES = MAIN_LDS > OUT_LDS ? MAIN_LDS : OUT_LDS;
@@ -87,7 +85,7 @@ struct BwdCfg {
 
 template <int DP, bool BF16>
 __global__ void __launch_bounds__(BW_NT, 1)
-bwd_main_kernel(const KParams p, const int n_kblocks) {
+bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP>;
     constexpr int CPR = Cfg::CPR;
     constexpr int KS = DP / 16, NDB = DP / 32;
@@ -99,12 +97,28 @@ bwd_main_kernel(const KParams p, const int n_kblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
 
-    // block -> (batch, kv head, key block); low key blocks (most query rows under a causal mask)
-    // are dispatched first
-    int L = blockIdx.x;
-    const int n_block = L % n_kblocks; L /= n_kblocks;
-    const int hk = L % p.h_k;
-    const int bidb = L / p.h_k;
+    // block -> (batch, kv head, key block).  Blocks b and b+8 share an XCD (round-robin dispatch):
+    // give each XCD whole (batch, kv head) pairs, so the key blocks of a pair run side by side on
+    // one XCD and the Q / dO slices they all sweep (in the same order, see below) are L2 hits for
+    // every block but the first.
+    int n_block, hk, bidb;
+    {
+        const int P = p.b * p.h_k;
+        const int L = blockIdx.x;
+        const int full = (P / 8) * 8 * n_kblocks;
+        int pair;
+        if (L < full) {
+            const int x = L & 7, sl = L >> 3;
+            pair = (sl / n_kblocks) * 8 + x;
+            n_block = sl % n_kblocks;
+        } else {
+            const int Lr = L - full;
+            pair = (P / 8) * 8 + Lr / n_kblocks;
+            n_block = Lr % n_kblocks;
+        }
+        hk = pair % p.h_k;
+        bidb = pair / p.h_k;
+    }
 
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
@@ -159,7 +173,9 @@ bwd_main_kernel(const KParams p, const int n_kblocks) {
     i32x4 qreg[QCH], doreg[QCH];
     float rowc = 0.f;  // lse (tid < 32) or delta (32 <= tid < 64) of the slice
     auto head_of = [&](int step) { return hk * p.h_ratio + step / n_steps_per_head; };
-    auto m_of = [&](int step) { return m_min + step % n_steps_per_head; };
+    // query slices are swept from the last one down: under a causal mask every key block sees the
+    // last rows, so the co-resident blocks of a pair read the same slice at about the same time
+    auto m_of = [&](int step) { return m_max - 1 - step % n_steps_per_head; };
     auto load_slice = [&](int step) {
         const int bidh = head_of(step), q0 = m_of(step) * BW_QM;
         const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
@@ -198,7 +214,6 @@ bwd_main_kernel(const KParams p, const int n_kblocks) {
     if (total_steps > 0) store_slice(0);
     __syncthreads();
 
-    float *dqa_base = p.dq_accum;
     int buf = 0;
     for (int step = 0; step < total_steps; step++) {
         const int bidh = head_of(step), q0 = m_of(step) * BW_QM;
@@ -269,18 +284,6 @@ bwd_main_kernel(const KParams p, const int n_kblocks) {
                 pf[ks2][w] = pack2<BF16>(s[8 * ks2 + 2 * w], s[8 * ks2 + 2 * w + 1]);
                 dsf[ks2][w] = pack2<BF16>(dp[8 * ks2 + 2 * w], dp[8 * ks2 + 2 * w + 1]);
             }
-        // dS^T image for dQ: lane (key r) stores 4 consecutive query rows (8 bytes) at [key][8 g4 + 4 hh]
-        {
-            char *dsb = smem + Cfg::OFF_DS + (32 * wave + r) * 64;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                i32x2 w2;
-                w2[0] = dsf[g4 >> 1][2 * (g4 & 1)];
-                w2[1] = dsf[g4 >> 1][2 * (g4 & 1) + 1];
-                *(i32x2 *)(dsb + (8 * g4 + 4 * hh) * 2) = w2;
-            }
-        }
-
         // ---- dV^T += dO^T P,  dK^T += Q^T dS  (A operands by transposed reads of the slice) ----
 #pragma unroll
         for (int db = 0; db < NDB; db++) {
@@ -300,42 +303,6 @@ bwd_main_kernel(const KParams p, const int n_kblocks) {
                 dk[db] = mma32<BF16>(qt, dsf[ks2], dk[db]);
             }
         }
-        __syncthreads();  // dS^T of all four waves is in LDS
-
-        // ---- dQ[32 q][32 d slice] = dS[32 q][128 keys] K[128 keys][d slice]; d slices round-robin
-        // over the waves ----
-        for (int db = wave; db < NDB; db += BW_NW) {
-            f32x16 dq;
-#pragma unroll
-            for (int j = 0; j < 16; j++) dq[j] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < BW_KB / 16; ks++) {
-                const int key0 = 16 * ks + 4 * hh + tr_q;
-                // A = dS (32 q x 16 keys): transposed read of the [key][q] image, 16 q per lane group
-                const char *dsb = smem + Cfg::OFF_DS;
-                const int qo = (16 * tr_g + 4 * tr_p) * 2;
-                const i32x2 a0 = __builtin_bit_cast(i32x2, lds_read_tr16(dsb + key0 * 64 + qo));
-                const i32x2 a1 = __builtin_bit_cast(i32x2, lds_read_tr16(dsb + (key0 + 8) * 64 + qo));
-                // B = K (16 keys x 32 d): transposed read of the K tile
-                const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
-                const i32x2 b0 = __builtin_bit_cast(i32x2, lds_read_tr16(smem + Cfg::OFF_K + lds_off<DP>(key0, ch) + 8 * (tr_p & 1)));
-                const i32x2 b1 = __builtin_bit_cast(i32x2, lds_read_tr16(smem + Cfg::OFF_K + lds_off<DP>(key0 + 8, ch) + 8 * (tr_p & 1)));
-                const i32x4 av = {a0[0], a0[1], a1[0], a1[1]};
-                const i32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
-                dq = mma32<BF16>(av, bv, dq);
-            }
-            // fp32 atomics: one register = two 128-byte row segments (rows differ by 4 between halves)
-            const int64_t row_base = (bi.sum_s_q < 0 ? (int64_t)bidb * p.seqlen_q : (int64_t)bi.sum_s_q);
-            float *dst = dqa_base + ((row_base + q0) * p.h + bidh) * (int64_t)p.d + 32 * db + r;
-            if (32 * db + r < p.d) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    if (q0 + row < sq) unsafeAtomicAdd(dst + (int64_t)row * p.h * p.d, dq[j]);
-                }
-            }
-        }
-
         if (has_next) store_slice(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -376,34 +343,241 @@ bwd_main_kernel(const KParams p, const int n_kblocks) {
     }
 }
 
-// dq = round16(scale * dq_accum); one thread per 8-wide chunk
-template <bool BF16>
-__global__ void __launch_bounds__(256)
-bwd_convert_dq_kernel(const KParams p) {
-    const int cpr = p.d / 8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)p.b * p.seqlen_q * p.h * cpr;
-    if (idx >= total) return;
-    const int ch = (int)(idx % cpr);
-    int64_t t = idx / cpr;
-    const int bidh = (int)(t % p.h); t /= p.h;
-    const int sqi = (int)(t % p.seqlen_q);
-    const int bidb = (int)(t / p.seqlen_q);
+// ---------------------------------------------------------------------------------------------
+// dQ: query-stationary.  Same staging, swizzles and fragment maps as the forward prefill kernel.
+constexpr int DQ_BN = 64;
+
+template <int DP, int NW>
+struct DqCfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int BM = NW * 32;
+    static constexpr int CPR = DP / 8;
+    static constexpr int CH = DQ_BN * CPR / NT;
+    static constexpr int TILE_BYTES = DQ_BN * DP * 2;
+    static constexpr int O_ROWB = DP * 2 + 16;
+    static constexpr int KV_LDS = 4 * TILE_BYTES;
+    static constexpr int O_LDS = NW * 32 * O_ROWB;
+    static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+};
+
+template <int DP, bool BF16, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
+bwd_dq_kernel(const KParams p, const int n_mblocks) {
+    using Cfg = DqCfg<DP, NW>;
+    constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
+    constexpr int KS = DP / 16, NDB = DP / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+
+    // block -> (batch, head, m_block): whole (batch, kv head) pairs per XCD, heavy m-blocks first
+    int bidb, bidh, m_block;
+    {
+        const int g = p.h_ratio;
+        const int W = g * n_mblocks;
+        const int P = p.b * p.h_k;
+        const int L = blockIdx.x;
+        const int full = (P / 8) * 8 * W;
+        int pair, item;
+        if (L < full) {
+            const int x = L & 7, s = L >> 3;
+            pair = (s / W) * 8 + x;
+            item = s % W;
+        } else {
+            const int Lr = L - full;
+            pair = (P / 8) * 8 + Lr / W;
+            item = Lr % W;
+        }
+        bidb = pair / p.h_k;
+        const int hk_ = pair % p.h_k;
+        bidh = hk_ * g + item % g;
+        m_block = n_mblocks - 1 - item / g;
+    }
+    const int hk = bidh / p.h_ratio;
     const BlockInfo bi(p, bidb);
-    if (sqi >= bi.sq) return;
-    const int64_t row_base = bi.sum_s_q < 0 ? (int64_t)bidb * p.seqlen_q : (int64_t)bi.sum_s_q;
-    const float *src = p.dq_accum + ((row_base + sqi) * p.h + bidh) * (int64_t)p.d + ch * 8;
-    const f32x4 a0 = *(const f32x4 *)src * p.scale, a1 = *(const f32x4 *)(src + 4) * p.scale;
-    unsigned short *dst = (unsigned short *)p.dq + bi.q_off(p.dq_bs, p.dq_rs, bidb) + (int64_t)sqi * p.dq_rs +
-                          (int64_t)bidh * p.dq_hs + ch * 8;
-    i32x4 w;
-    w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
-    w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
-    *(i32x4 *)dst = w;
+    const int sq = bi.sq, sk = bi.sk;
+    if (m_block * BM >= sq) return;
+
+    int n_min = !p.is_local ? 0 : max(0, (m_block * BM + sk - sq - p.wl) / DQ_BN);
+    int n_max = (sk + DQ_BN - 1) / DQ_BN;
+    if (p.is_causal || p.is_local)
+        n_max = min(n_max, ((m_block + 1) * BM + sk - sq + p.wr + DQ_BN - 1) / DQ_BN);
+
+    const int q0w = m_block * BM + wave * 32;
+    const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
+    const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
+    unsigned short *dqg = (unsigned short *)p.dq + bi.q_off(p.dq_bs, p.dq_rs, bidb) + (int64_t)bidh * p.dq_hs;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) dq[i][j] = 0.f;
+
+    if (n_max > n_min) {
+        const unsigned short *kg = (const unsigned short *)p.k + bi.k_off(p.k_bs, p.k_rs, bidb) + (int64_t)hk * p.k_hs;
+        const unsigned short *vg = (const unsigned short *)p.v + bi.k_off(p.v_bs, p.v_rs, bidb) + (int64_t)hk * p.v_hs;
+        i32x4 kreg[CH], vreg[CH];
+        auto load_tile = [&](int n) {
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int c = tid + i * NT;
+                const int row = c / CPR, ch = c % CPR;
+                const int grow = n * DQ_BN + row;
+                const bool ok = grow < sk && ch * 8 < p.d;
+                kreg[i] = ok ? *(const i32x4 *)(kg + (int64_t)grow * p.k_rs + ch * 8) : i32x4{0, 0, 0, 0};
+                vreg[i] = ok ? *(const i32x4 *)(vg + (int64_t)grow * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            }
+        };
+        auto store_tile = [&](int buf) {
+            char *kb = smem + buf * Cfg::TILE_BYTES;
+            char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int c = tid + i * NT;
+                const int off = lds_off<DP>(c / CPR, c % CPR);
+                *(i32x4 *)(kb + off) = kreg[i];
+                *(i32x4 *)(vb + off) = vreg[i];
+            }
+        };
+
+        // Q^T and dO^T B-operand fragments; LSE and delta of this lane's query row
+        i32x4 qf[KS], dof[KS];
+        float lse_r = INFINITY, dl_r = 0.f;
+        {
+            const int row = q0w + r;
+            const bool rok = row < sq;
+            const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+            const unsigned short *dr = dog + (int64_t)(rok ? row : 0) * p.do_rs;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const int col = 16 * s + 8 * hh;
+                const bool ok = rok && col < p.d;
+                qf[s] = ok ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
+                dof[s] = ok ? *(const i32x4 *)(dr + col) : i32x4{0, 0, 0, 0};
+            }
+            if (rok) {
+                lse_r = p.lse[((int64_t)bidb * p.h + bidh) * p.seqlen_q + row];
+                dl_r = p.dsoftmax_sum[((int64_t)bidb * p.h + bidh) * p.seqlen_q_rounded + row];
+            }
+        }
+        const float lse2 = lse_r * (float)M_LOG2E;
+        float alibi = 0.f;
+        const bool has_alibi = p.alibi_slopes != nullptr;
+        if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
+        const float c2 = p.scale_log2;
+        const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+
+        load_tile(n_max - 1);
+        store_tile(0);
+        __syncthreads();
+        int buf = 0;
+        for (int n = n_max - 1; n >= n_min; n--) {
+            const bool has_next = n > n_min;
+            if (has_next) load_tile(n - 1);
+            const char *kb = smem + buf * Cfg::TILE_BYTES;
+            const char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+            const int c0 = n * DQ_BN;
+            bool need = has_alibi || (c0 + DQ_BN > sk);
+            if (p.is_causal || p.is_local) need = need || (c0 + DQ_BN > q0w + 1 + sk - sq + p.wr);
+            if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; kb2++) {
+                // S^T and dP'^T = V dO^T - delta for 32 keys; the query is on the lane
+                f32x16 s, dp;
+#pragma unroll
+                for (int j = 0; j < 16; j++) { s[j] = 0.f; dp[j] = -dl_r; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const int off = lds_off<DP>(32 * kb2 + r, 2 * ks + hh);
+                    s = mma32<BF16>(*(const i32x4 *)(kb + off), qf[ks], s);
+                    dp = mma32<BF16>(*(const i32x4 *)(vb + off), dof[ks], dp);
+                }
+                if (need) {
+                    const int row = q0w + r;
+                    const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
+                    const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int col = c0 + 32 * kb2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                        float x = s[j];
+                        if (has_alibi)
+                            x = p.is_causal ? x + alibi * (float)col
+                                            : x - alibi * fabsf((float)(row + sk - sq - col));
+                        s[j] = (col >= lo && col < hi) ? x : -INFINITY;
+                    }
+                }
+                i32x4 dsf[2];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j], c2, -lse2));
+                    dp[j] = pe * dp[j];
+                }
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+                        dsf[ks2][w] = pack2<BF16>(dp[8 * ks2 + 2 * w], dp[8 * ks2 + 2 * w + 1]);
+                // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+                for (int db = 0; db < NDB; db++) {
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 2; ks2++) {
+                        const int row0 = 32 * kb2 + 16 * ks2 + 4 * hh + tr_q;
+                        const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
+                        const i32x2 a0 = __builtin_bit_cast(i32x2, lds_read_tr16(kb + lds_off<DP>(row0, ch) + 8 * (tr_p & 1)));
+                        const i32x2 a1 = __builtin_bit_cast(i32x2, lds_read_tr16(kb + lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1)));
+                        const i32x4 kt = {a0[0], a0[1], a1[0], a1[1]};
+                        dq[db] = mma32<BF16>(kt, dsf[ks2], dq[db]);
+                    }
+                }
+            }
+            if (has_next) store_tile(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- dq = round16(scale * dQ), stored through LDS as whole rows ----
+    __syncthreads();
+    char *ob = smem + wave * 32 * Cfg::O_ROWB;
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            i32x2 w;
+            w[0] = pack2<BF16>(dq[db][4 * g4 + 0] * p.scale, dq[db][4 * g4 + 1] * p.scale);
+            w[1] = pack2<BF16>(dq[db][4 * g4 + 2] * p.scale, dq[db][4 * g4 + 3] * p.scale);
+            *(i32x2 *)(ob + r * Cfg::O_ROWB + (32 * db + 8 * g4 + 4 * hh) * 2) = w;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (32 * CPR) / 64; i++) {
+        const int c = lane + 64 * i;
+        const int row = c / CPR, ch = c % CPR;
+        const i32x4 w = *(const i32x4 *)(ob + row * Cfg::O_ROWB + ch * 16);
+        if (q0w + row < sq && ch * 8 < p.d)
+            *(i32x4 *)(dqg + (int64_t)(q0w + row) * p.dq_rs + ch * 8) = w;
+    }
 }
 
-// dk / dv rows of key blocks that no workgroup visits cannot exist (every key block < sk has a
-// workgroup); rows of keys no query can see get zeros from the zero-initialised accumulators.
+template <int DP, bool BF16, int NW>
+static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
+    using Cfg = DqCfg<DP, NW>;
+    const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
+    const long long blocks = (long long)n_mblocks * p.b * p.h;
+    if (blocks <= 0) return hipSuccess;
+    auto kern = bwd_dq_kernel<DP, BF16, NW>;
+    if (Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
+    return hipGetLastError();
+}
 
 template <int DP, bool BF16>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
@@ -418,7 +592,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (blocks > 0) {
-        auto kern = bwd_main_kernel<DP, BF16>;
+        auto kern = bwd_dkdv_kernel<DP, BF16>;
         if (Cfg::LDS_BYTES > 64 * 1024) {
             e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
             if (e != hipSuccess) return e;
@@ -427,8 +601,10 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
     {
-        const int64_t items = (int64_t)p.b * p.seqlen_q * p.h * (p.d / 8);
-        hipLaunchKernelGGL(bwd_convert_dq_kernel<BF16>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p);
+        const bool big = p.seqlen_q > 128;
+        if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
+        else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
+        if (e != hipSuccess) return e;
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
     return hipGetLastError();
