@@ -27,9 +27,6 @@
 
 namespace vfa {
 
-constexpr int BW_NW = 4;
-constexpr int BW_NT = BW_NW * 64;
-constexpr int BW_KB = 32 * BW_NW;  // keys per workgroup
 constexpr int BW_QM = 32;          // query rows per step
 
 template <bool BF16>
@@ -64,32 +61,43 @@ bwd_preprocess_kernel(const KParams p) {
     if (lane16 == 0) p.dsoftmax_sum[(int64_t)bh * p.seqlen_q_rounded + sqi] = acc;
 }
 
-template <int DP>
+// dK/dV kernel geometry.  NW waves x 32 keys per workgroup.  NW = 8 (two waves per SIMD, <= 256
+// registers each): K fragments live in registers, V fragments are re-read from the V tile that
+// stays in LDS.  NW = 4 (one wave per SIMD, for short key sequences): K and V fragments both in
+// registers, the V tile's LDS space is reused for the Q / dO slices.
+template <int DP, int NW>
 struct BwdCfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int KB = NW * 32;                        // keys per workgroup
+    static constexpr bool V_IN_LDS = NW == 8;
     static constexpr int CPR = DP / 8;
-    static constexpr int KV_BYTES = BW_KB * DP * 2;          // one of K / V
-    static constexpr int QT_BYTES = BW_QM * DP * 2;          // one of Q / dO slice
-    static constexpr int QBUF_BYTES = 2 * QT_BYTES + 256;    // Q, dO, lse[32], delta[32]
+    static constexpr int KV_BYTES = KB * DP * 2;              // one of K / V
+    static constexpr int QT_BYTES = BW_QM * DP * 2;           // one of Q / dO slice
+    static constexpr int QBUF_BYTES = 2 * QT_BYTES + 256;     // Q, dO, lse[32], delta[32]
+    // LDS map: [K tile | V tile] while loading; then V_IN_LDS: [Q bufs (over K) ... | V tile],
+    // else: [unused K | Q bufs (over V)]
     static constexpr int OFF_K = 0;
     static constexpr int OFF_V = KV_BYTES;
-    static constexpr int OFF_Q = KV_BYTES;                   // two Q buffers; they reuse the V tile's
-                                                             // space once V is in registers
-    static constexpr int MAIN_LDS = OFF_Q + (2 * QBUF_BYTES > KV_BYTES ? 2 * QBUF_BYTES : KV_BYTES);
+    static constexpr int OFF_Q = V_IN_LDS ? 0 : KV_BYTES;
+    static constexpr int QSPACE = 2 * QBUF_BYTES > KV_BYTES ? 2 * QBUF_BYTES : KV_BYTES;
+    static constexpr int MAIN_LDS = V_IN_LDS ? (QSPACE > KV_BYTES ? QSPACE + KV_BYTES : 2 * KV_BYTES)
+                                             : KV_BYTES + QSPACE;
+    static constexpr int OFF_VT = V_IN_LDS ? (QSPACE > KV_BYTES ? QSPACE : KV_BYTES) : KV_BYTES;
     static constexpr int OUT_ROWB = DP * 2 + 16;
-    static constexpr int OUT_LDS = BW_NW * 32 * OUT_ROWB;
+    static constexpr int OUT_LDS = NW * 32 * OUT_ROWB;
     static constexpr int LDS_BYTES = MAIN_LDS > OUT_LDS ? MAIN_LDS : OUT_LDS;
-    static constexpr int KV_CH = BW_KB * CPR / BW_NT;        // chunks per thread per K (or V) tile
-    static constexpr int Q_CH = BW_QM * CPR / BW_NT;         // chunks per thread per Q (or dO) slice
-    static_assert(BW_QM * CPR % BW_NT == 0 || BW_QM * CPR < BW_NT, "slice must divide over threads");
+    static constexpr int KV_CH = KB * CPR / NT;               // chunks per thread per K (or V) tile
+    static constexpr int QCH = (BW_QM * CPR + NT - 1) / NT;   // chunks per thread per Q (or dO) slice
 };
 
-template <int DP, bool BF16>
-__global__ void __launch_bounds__(BW_NT, 1)
+template <int DP, bool BF16, int NW>
+__global__ void __launch_bounds__(NW * 64, 1)
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
-    using Cfg = BwdCfg<DP>;
-    constexpr int CPR = Cfg::CPR;
+    using Cfg = BwdCfg<DP, NW>;
+    constexpr int CPR = Cfg::CPR, NT = Cfg::NT, KB = Cfg::KB;
     constexpr int KS = DP / 16, NDB = DP / 32;
-    constexpr int QCH = (BW_QM * CPR + BW_NT - 1) / BW_NT;
+    constexpr int QCH = Cfg::QCH;
+    constexpr bool V_IN_LDS = Cfg::V_IN_LDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -122,40 +130,42 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
 
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
-    const int k0 = n_block * BW_KB;
+    const int k0 = n_block * KB;
     if (k0 >= sk) return;
     const int kw0 = k0 + 32 * wave;  // first key of this wave
 
     // query-slice range that can see this key block
     int m_min = 0, m_max = (sq + BW_QM - 1) / BW_QM;
     if (p.is_causal || p.is_local) m_min = max(0, (k0 + sq - sk - p.wr) / BW_QM);
-    if (p.is_local) m_max = min(m_max, (k0 + BW_KB + sq - sk + p.wl + BW_QM - 1) / BW_QM);
+    if (p.is_local) m_max = min(m_max, (k0 + KB + sq - sk + p.wl + BW_QM - 1) / BW_QM);
 
     const unsigned short *kg = (const unsigned short *)p.k + bi.k_off(p.k_bs, p.k_rs, bidb) + (int64_t)hk * p.k_hs;
     const unsigned short *vg = (const unsigned short *)p.v + bi.k_off(p.v_bs, p.v_rs, bidb) + (int64_t)hk * p.v_hs;
 
-    // ---- stage K and V (128 keys) into LDS; zero rows past sk ----
+    // ---- stage K and V into LDS; zero rows past sk ----
     {
 #pragma unroll
         for (int i = 0; i < Cfg::KV_CH; i++) {
-            const int c = tid + i * BW_NT;
+            const int c = tid + i * NT;
             const int row = c / CPR, ch = c % CPR;
             const bool ok = (k0 + row) < sk && ch * 8 < p.d;
             const i32x4 kk = ok ? *(const i32x4 *)(kg + (int64_t)(k0 + row) * p.k_rs + ch * 8) : i32x4{0, 0, 0, 0};
             const i32x4 vv = ok ? *(const i32x4 *)(vg + (int64_t)(k0 + row) * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
             const int off = lds_off<DP>(row, ch);
             *(i32x4 *)(smem + Cfg::OFF_K + off) = kk;
-            *(i32x4 *)(smem + Cfg::OFF_V + off) = vv;
+            *(i32x4 *)(smem + Cfg::OFF_VT + off) = vv;
         }
     }
     __syncthreads();
     // B-operand fragments of this wave's 32 keys: lane (r, hh) holds K[kw0 + r][16 s + 8 hh ..]
-    i32x4 kf[KS], vf[KS];
+    i32x4 kf[KS], vf[V_IN_LDS ? 1 : KS];
 #pragma unroll
     for (int s = 0; s < KS; s++) {
         kf[s] = *(const i32x4 *)(smem + Cfg::OFF_K + lds_off<DP>(32 * wave + r, 2 * s + hh));
-        vf[s] = *(const i32x4 *)(smem + Cfg::OFF_V + lds_off<DP>(32 * wave + r, 2 * s + hh));
+        if constexpr (!V_IN_LDS)
+            vf[s] = *(const i32x4 *)(smem + Cfg::OFF_VT + lds_off<DP>(32 * wave + r, 2 * s + hh));
     }
+    const char *vt = smem + Cfg::OFF_VT;
 
     f32x16 dk[NDB], dv[NDB];
 #pragma unroll
@@ -182,7 +192,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
 #pragma unroll
         for (int i = 0; i < QCH; i++) {
-            const int c = tid + i * BW_NT;
+            const int c = tid + i * NT;
             const int row = c / CPR, ch = c % CPR;
             const bool ok = c < BW_QM * CPR && (q0 + row) < sq && ch * 8 < p.d;
             qreg[i] = ok ? *(const i32x4 *)(qg + (int64_t)(q0 + row) * p.q_rs + ch * 8) : i32x4{0, 0, 0, 0};
@@ -199,7 +209,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
 #pragma unroll
         for (int i = 0; i < QCH; i++) {
-            const int c = tid + i * BW_NT;
+            const int c = tid + i * NT;
             if (c < BW_QM * CPR) {
                 const int off = lds_off<DP>(c / CPR, c % CPR);
                 *(i32x4 *)(qb + off) = qreg[i];
@@ -210,7 +220,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     };
 
     if (total_steps > 0) load_slice(0);
-    __syncthreads();  // every wave has its V fragments: the V tile's space becomes the Q buffers
+    __syncthreads();  // every wave has its fragments: the freed tile space becomes the Q buffers
     if (total_steps > 0) store_slice(0);
     __syncthreads();
 
@@ -225,26 +235,16 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         const float *lse_s = (const float *)(qb + 2 * Cfg::QT_BYTES);
         const float *dl_s = lse_s + 32;
 
-        // ---- S[q][key] = Q K^T, dP'[q][key] = dO V^T - delta[q]; key on the lane ----
-        f32x16 s, dp;
+        // ---- S[q][key] = Q K^T; key on the lane ----
+        f32x16 s;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-            const f32x4 dl = *(const f32x4 *)(dl_s + 8 * g4 + 4 * hh);
-#pragma unroll
-            for (int t = 0; t < 4; t++) { s[4 * g4 + t] = 0.f; dp[4 * g4 + t] = -dl[t]; }
-        }
+        for (int j = 0; j < 16; j++) s[j] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const i32x4 qa = *(const i32x4 *)(qb + lds_off<DP>(r, 2 * ks + hh));
             s = mma32<BF16>(qa, kf[ks], s);
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const i32x4 da = *(const i32x4 *)(dob + lds_off<DP>(r, 2 * ks + hh));
-            dp = mma32<BF16>(da, vf[ks], dp);
-        }
-
-        // ---- P = exp2(S*c - LSE*log2e) under the forward's mask and bias; dS = P * dP' ----
+        // ---- P = exp2(S*c - LSE*log2e) under the forward's mask and bias ----
         {
             const int col = kw0 + r;
             float alibi = 0.f;
@@ -252,28 +252,42 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const bool masked_tile = has_alibi || (kw0 + 32 > sk) || (q0 + 32 > sq) ||
                                      ((p.is_causal || p.is_local) && (kw0 + 32 > q0 + 1 + sk - sq + p.wr)) ||
                                      (p.is_local && (kw0 < q0 + 31 + sk - sq - p.wl));
+            if (masked_tile) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int row = q0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                    float x = s[j];
+                    if (has_alibi)
+                        x = p.is_causal ? x + alibi * (float)col
+                                        : x - alibi * fabsf((float)(row + sk - sq - col));
+                    const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
+                    const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
+                    s[j] = (col >= lo && col < hi && row < sq) ? x : -INFINITY;
+                }
+            }
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 const f32x4 ls = *(const f32x4 *)(lse_s + 8 * g4 + 4 * hh);
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int j = 4 * g4 + t;
-                    float x = s[j];
-                    bool vis = true;
-                    if (masked_tile) {
-                        const int row = q0 + 8 * g4 + 4 * hh + t;
-                        if (has_alibi)
-                            x = p.is_causal ? x + alibi * (float)col
-                                            : x - alibi * fabsf((float)(row + sk - sq - col));
-                        const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
-                        const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
-                        vis = col >= lo && col < hi && row < sq;
-                    }
-                    const float pe = vis ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, c2, -ls[t] * (float)M_LOG2E)) : 0.f;
-                    s[j] = pe;
-                    dp[j] = pe * dp[j];
-                }
+                for (int t = 0; t < 4; t++)
+                    s[4 * g4 + t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * g4 + t], c2, -ls[t] * (float)M_LOG2E));
             }
+        }
+        // ---- dP'[q][key] = dO V^T - delta[q];  dS = P * dP' ----
+        f32x16 dp;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const f32x4 dl = *(const f32x4 *)(dl_s + 8 * g4 + 4 * hh);
+#pragma unroll
+            for (int t = 0; t < 4; t++) dp[4 * g4 + t] = -dl[t];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const i32x4 da = *(const i32x4 *)(dob + lds_off<DP>(r, 2 * ks + hh));
+            i32x4 vb;
+            if constexpr (V_IN_LDS) vb = *(const i32x4 *)(vt + lds_off<DP>(32 * wave + r, 2 * ks + hh));
+            else vb = vf[ks];
+            dp = mma32<BF16>(da, vb, dp);
         }
         // 16-bit B operands: k-step ks2 (16 query rows) = regs 8 ks2 .. 8 ks2 + 7
         i32x4 pf[2], dsf[2];
@@ -281,9 +295,11 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         for (int ks2 = 0; ks2 < 2; ks2++)
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                pf[ks2][w] = pack2<BF16>(s[8 * ks2 + 2 * w], s[8 * ks2 + 2 * w + 1]);
-                dsf[ks2][w] = pack2<BF16>(dp[8 * ks2 + 2 * w], dp[8 * ks2 + 2 * w + 1]);
+                const int j = 8 * ks2 + 2 * w;
+                pf[ks2][w] = pack2<BF16>(s[j], s[j + 1]);
+                dsf[ks2][w] = pack2<BF16>(s[j] * dp[j], s[j + 1] * dp[j + 1]);
             }
+
         // ---- dV^T += dO^T P,  dK^T += Q^T dS  (A operands by transposed reads of the slice) ----
 #pragma unroll
         for (int db = 0; db < NDB; db++) {
@@ -303,6 +319,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                 dk[db] = mma32<BF16>(qt, dsf[ks2], dk[db]);
             }
         }
+
         if (has_next) store_slice(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -341,6 +358,21 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }
         __syncthreads();
     }
+}
+
+template <int DP, bool BF16, int NW>
+static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
+    using Cfg = BwdCfg<DP, NW>;
+    const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
+    const long long blocks = (long long)n_kblocks * p.b * p.h_k;
+    if (blocks <= 0) return hipSuccess;
+    auto kern = bwd_dkdv_kernel<DP, BF16, NW>;
+    if (Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_kblocks);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,24 +613,16 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
 
 template <int DP, bool BF16>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
-    using Cfg = BwdCfg<DP>;
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[0], stream);
     {
         const int64_t rows = (int64_t)p.b * p.h * p.seqlen_q;
         hipLaunchKernelGGL(bwd_preprocess_kernel<BF16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p);
     }
-    const int n_kblocks = (p.seqlen_k + BW_KB - 1) / BW_KB;
-    const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    if (blocks > 0) {
-        auto kern = bwd_dkdv_kernel<DP, BF16>;
-        if (Cfg::LDS_BYTES > 64 * 1024) {
-            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW_NT), Cfg::LDS_BYTES, stream, p, n_kblocks);
-    }
+    if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4>(p, stream);
+    else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8>(p, stream) : launch_dkdv<DP, BF16, 4>(p, stream);
+    if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[2], stream);
     {
         const bool big = p.seqlen_q > 128;
