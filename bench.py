@@ -65,6 +65,41 @@ class Hip:
         return ms.value
 
 
+def shard_range(n, world, rank):
+    """Contiguous shard [start, stop) of n independent batch entries for `rank` of `world`
+    (sizes differ by at most one).  The attention op has no cross-batch dependency, so this is the
+    whole multi-GPU decomposition: no collective touches the data path."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def dist_setup(backend):
+    """Joins the process group when launched by torch.distributed.run; returns (dist or None, rank,
+    world, local_rank).  The group is used only for the timing barrier and the max-over-ranks."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return None, rank, world, local_rank
+    import torch.distributed as dist
+    dist.init_process_group(backend)
+    return dist, rank, world, local_rank
+
+
+def max_over_ranks(dist, seconds, device):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def aggregate(work_per_rank_step, steps, world, elapsed_max, scale):
+    """Whole-job throughput: the work all ranks did divided by the slowest rank's time."""
+    return work_per_rank_step * steps * world / elapsed_max / scale
+
+
 def fwd_flops(b, sq, sk, h, d, causal):
     f = 4.0 * b * h * sq * sk * d
     return f / 2 if causal else f
@@ -139,16 +174,10 @@ def main():
     ap.add_argument("--no-sdpa", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL; used only for the timing barrier and max-reduce
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist, rank, world, local_rank = dist_setup("nccl")  # "nccl" is RCCL on ROCm
     import cabi
     cabi.lib()
     hip = Hip()
@@ -207,7 +236,7 @@ def main():
                 cabi.call("vfa_mha_fwd", Pf)
                 cabi.call("vfa_mha_bwd", Pb)
             work = 3.5 * f_fwd
-            kern_name = "bwd_main_kernel"
+            kern_name = "bwd_dkdv_kernel+bwd_dq_kernel"
         unit = "TFLOP/s"
         metric = ("attention fwd+bwd TFLOPS, seqlen 4096 headdim 128 bf16 causal" if args.workload == "c3"
                   else f"attention {mode} TFLOPS ({args.workload})")
@@ -221,11 +250,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    value = work * K * world / elapsed / scale
+    elapsed = max_over_ranks(dist, elapsed, dev)
+    value = aggregate(work, K, world, elapsed, scale)
 
     # ---- dominant-kernel duration with HIP events on the launch stream (rank 0, after the timed
     # region so that the region itself carries no instrumentation) ----
@@ -241,8 +267,18 @@ def main():
                 cabi.call("vfa_mha_bwd", Pb)
             Pb.stage_events = None
             torch.cuda.synchronize()
-            durs = [hip.elapsed_ms(C.c_void_p(e[1]), C.c_void_p(e[2])) for e in evs]
+            # the backward's algorithmic work (2.5 x forward) is done by two kernels: the
+            # key-stationary dK/dV kernel (events 1..2) and the query-stationary dQ kernel (2..3)
+            t_dkdv = [hip.elapsed_ms(C.c_void_p(e[1]), C.c_void_p(e[2])) for e in evs]
+            t_dq = [hip.elapsed_ms(C.c_void_p(e[2]), C.c_void_p(e[3])) for e in evs]
+            durs = [a + b_ for a, b_ in zip(t_dkdv, t_dq)]
             kwork = 2.5 * f_fwd
+            a1, a2 = sum(t_dkdv) / n, sum(t_dq) / n
+            extra["bwd_kernels"] = [
+                {"name": "bwd_dkdv_kernel", "avg_ms": a1, "executed_mfma_tflops": 2.0 * f_fwd / a1 / 1e9,
+                 "note": "4 MFMA products: S, dP, dV, dK"},
+                {"name": "bwd_dq_kernel", "avg_ms": a2, "executed_mfma_tflops": 1.5 * f_fwd / a2 / 1e9,
+                 "note": "3 MFMA products: S, dP (recomputed), dQ"}]
             fe = [(hip.event(), hip.event()) for _ in range(n)]
             for a, bb_ in fe:
                 hip.record(a, stream); cabi.call("vfa_mha_fwd", Pf); hip.record(bb_, stream)
