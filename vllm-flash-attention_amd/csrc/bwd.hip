@@ -235,6 +235,11 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         const float *lse_s = (const float *)(qb + 2 * Cfg::QT_BYTES);
         const float *dl_s = lse_s + 32;
 
+        // a wave whose 32 keys are invisible to all 32 rows of this slice only helps with staging
+        bool skip = false;
+        if (p.is_causal || p.is_local) skip = kw0 >= q0 + 32 + sk - sq + p.wr;
+        if (p.is_local) skip = skip || (kw0 + 32 <= q0 + sk - sq - p.wl);
+        if (!skip) {
         // ---- S[q][key] = Q K^T; key on the lane ----
         f32x16 s;
 #pragma unroll
@@ -319,6 +324,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                 dk[db] = mma32<BF16>(qt, dsf[ks2], dk[db]);
             }
         }
+        }  // !skip
 
         if (has_next) store_slice(buf ^ 1);
         __syncthreads();
@@ -518,6 +524,13 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
             if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
 #pragma unroll
             for (int kb2 = 0; kb2 < 2; kb2++) {
+                // skip 32-key halves none of this wave's rows can see (above its diagonal / left
+                // of its window); the wave still takes part in the staging
+                const int ch0 = c0 + 32 * kb2;
+                bool skip = false;
+                if (p.is_causal || p.is_local) skip = ch0 >= q0w + 32 + sk - sq + p.wr;
+                if (p.is_local) skip = skip || (ch0 + 32 <= q0w + sk - sq - p.wl);
+                if (skip) continue;
                 // S^T and dP'^T = V dO^T - delta for 32 keys; the query is on the lane
                 f32x16 s, dp;
 #pragma unroll

@@ -194,6 +194,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
         const char *kb = smem + buf * Cfg::TILE_BYTES;
         const char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+        const int c0 = n * BN;
+        // The tile range [n_min, n_max) is the block's; a wave whose 32 rows see none of this
+        // tile's keys (above its own diagonal, or left of its window) only helps with the staging.
+        bool skip = false;
+        if (p.is_causal || p.is_local) skip = c0 >= q0w + 32 + sk - sq + p.wr;
+        if (p.is_local) skip = skip || (c0 + BN <= q0w + sk - sq - p.wl);
+        if (!skip) {
 
         // ---- S^T = K Q^T : s[kb2][reg] = score(key = n*64 + 32 kb2 + (reg&3) + 8 (reg>>2) + 4 hh,
         //                                      query = q0w + r) ----
@@ -210,7 +217,6 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         }
 
         // ---- masks and ALiBi, only where needed (mask.h:128-209) ----
-        const int c0 = n * BN;
         bool need = has_alibi || (c0 + BN > sk);
         if (p.is_causal || p.is_local) need = need || (c0 + BN > q0w + 1 + sk - sq + p.wr);
         if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
@@ -285,6 +291,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 o[db] = mma32<BF16>(vf, pf[ks], o[db]);
             }
         }
+        }  // !skip
 
         if (has_next) store_tile(buf ^ 1);
         __syncthreads();
