@@ -36,7 +36,25 @@ WORKLOADS = {
     "c3_fwd": (8, 4096, 4096, 32, 32, 128, "bf16", True, "fwd"),
     "c2": (4, 2048, 2048, 16, 16, 64, "bf16", True, "fwd"),
     "c5": (128, 1, 8192, 32, 8, 128, "fp16", True, "decode"),
+    # flash_attn_varlen_func, ragged batch, GQA 32/8, sliding window (1024, 0) + ALiBi, causal
+    "c4": (8, 8192, 8192, 32, 8, 128, "bf16", True, "varlen_fwd"),
 }
+C4_SEQLENS = [8192, 6144, 4096, 3072, 2048, 1024, 513, 127]
+C4_WINDOW = (1024, 0)
+
+
+def visible_pairs(seqlens_q, seqlens_k, causal, window):
+    """Sum over rows of the number of visible keys (the masked FLOP count of SURVEY 8d)."""
+    wl, wr = window
+    if causal:
+        wr = 0
+    tot = 0
+    for sq, sk in zip(seqlens_q, seqlens_k):
+        for i in range(sq):
+            hi = sk if wr < 0 else min(sk, i + 1 + sk - sq + wr)
+            lo = 0 if wl < 0 else max(0, i + sk - sq - wl)
+            tot += max(0, hi - lo)
+    return tot
 
 
 class Hip:
@@ -130,6 +148,8 @@ def build_params(cabi, q, k, v, out, lse, causal, stream, do=None, dq=None, dk=N
 def cpu_baseline(name, b, sq, sk, h, hk, d, dtype, causal, mode):
     """The CPU oracle (a scalar C port of the reference algorithm, OpenMP over (batch, head)) timed
     on a bounded sample of the same workload: batch 1 and as many heads as threads."""
+    if mode == "varlen_fwd":
+        mode, sq, sk = "fwd", 2048, 2048  # sample: one 2048-token sequence of the ragged batch
     import numpy as np
     from oracle import fa_oracle
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
@@ -195,7 +215,33 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
-    if mode == "decode":
+    if mode == "varlen_fwd":
+        lens = C4_SEQLENS
+        total = sum(lens)
+        cu = torch.tensor([0] + list(__import__("itertools").accumulate(lens)), dtype=torch.int32, device=dev)
+        q = torch.randn(total, h, d, device=dev, dtype=tdt)
+        k = torch.randn(total, hk, d, device=dev, dtype=tdt)
+        v = torch.randn(total, hk, d, device=dev, dtype=tdt)
+        slopes = torch.rand(len(lens), h, device=dev, dtype=torch.float32) * 0.3
+        out = torch.empty_like(q)
+        lse = torch.empty(len(lens), h, max(lens), device=dev, dtype=torch.float32)
+        P = cabi.VfaParams()
+        P.dtype = 1
+        P.q, P.k, P.v, P.out, P.softmax_lse = (t.data_ptr() for t in (q, k, v, out, lse))
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+            cabi._set4(P, name, t, False)
+        P.b, P.seqlen_q, P.seqlen_k, P.h, P.h_k, P.d = len(lens), max(lens), max(lens), h, hk, d
+        P.cu_seqlens_q = P.cu_seqlens_k = cu.data_ptr()
+        P.is_seqlens_k_cumulative = 1
+        P.alibi_slopes, P.alibi_slopes_batch_stride = slopes.data_ptr(), slopes.stride(0)
+        P.softmax_scale = d ** -0.5
+        P.is_causal, P.window_size_left, P.window_size_right = 1, C4_WINDOW[0], C4_WINDOW[1]
+        P.num_splits, P.stream = 1, stream
+        step = lambda: cabi.call("vfa_mha_varlen_fwd", P)
+        work = 4.0 * h * d * visible_pairs(lens, lens, True, C4_WINDOW)
+        unit, metric = "TFLOP/s", "varlen GQA 32/8 d128 window(1024,0)+ALiBi causal fwd TFLOPS (masked FLOPs)"
+        kern_name, bound, peak, scale = "fwd_prefill_kernel", "mfma", PEAK_TFLOPS_BF16, 1e12
+    elif mode == "decode":
         q = torch.randn(b, 1, h, d, device=dev, dtype=tdt)
         kc = torch.randn(b, sk, hk, d, device=dev, dtype=tdt)
         vc = torch.randn(b, sk, hk, d, device=dev, dtype=tdt)
@@ -299,7 +345,7 @@ def main():
                 "unit": unit, "frac": achieved / peak, "avg_kernel_ms": avg, "traffic": None}
 
     # ---- torch SDPA on the same GPU and inputs (rank 0) ----
-    if rank == 0 and not args.no_sdpa and mode != "decode":
+    if rank == 0 and not args.no_sdpa and mode in ("fwd", "fwd_bwd"):
         import torch.nn.functional as F
         qt, kt, vt = (x.transpose(1, 2).detach().requires_grad_(mode == "fwd_bwd") for x in (q, k, v))
         gt = torch.randn_like(qt)

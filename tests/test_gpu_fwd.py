@@ -316,3 +316,72 @@ def test_error_messages_match_reference():
     bt = torch.zeros(1, 2, dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="divisible by 16"):
         fa.flash_attn_with_kvcache(q, kc, kc, block_table=bt, cache_seqlens=3)
+
+
+def test_config2_shape_slices_vs_oracle():
+    """BASELINE config 2 (b4 s2048 h16 d64 bf16 causal, fwd): head slices against the oracle."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    torch.manual_seed(0)
+    b, s, h, d = 4, 2048, 16, 64
+    q, k, v = (torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    out, lse = _cabi().fwd(q, k, v, causal=True)
+    for bb, hh in ((0, 0), (3, 15)):
+        sl = lambda t: t[bb:bb + 1, :, hh:hh + 1].float().cpu().numpy()
+        ro, rl = fa_oracle.attention_fwd(sl(q), sl(k), sl(v), dtype="bf16", causal=True)
+        assert np.abs(sl(out) - ro).max() <= ulp_tol("bf16", ro)
+        assert np.abs(lse[bb:bb + 1, hh:hh + 1].cpu().numpy() - rl).max() <= 1e-3
+
+
+def test_config4_varlen_gqa_window_alibi():
+    """BASELINE config 4: flash_attn_varlen_func, GQA 32/8, d128 bf16, ragged seqlens up to 8192,
+    causal + window (1024, 0) + ALiBi.  Full batch on the GPU; parity vs the oracle on the short
+    sequences (all heads) and on one head of the longest sequences; a sequence computed alone is
+    bitwise equal to its slice of the batched call."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(0)
+    lens = [8192, 6144, 4096, 3072, 2048, 1024, 513, 127]
+    h, hk, d = 32, 8, 128
+    total = sum(lens)
+    cu = _cu(lens)
+    q = torch.randn(total, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(total, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(total, hk, d, device="cuda", dtype=torch.bfloat16)
+    slopes = torch.rand(len(lens), h, device="cuda") * 0.3
+    out, lse, _ = fa.flash_attn_varlen_func(q, k, v, cu, cu, max(lens), max(lens), causal=True,
+                                            window_size=(1024, 0), alibi_slopes=slopes, return_attn_probs=True)
+    assert torch.isfinite(out.float()).all()
+    cuh = cu.cpu().numpy()
+    f = lambda t: t.float().cpu().numpy()
+    # The oracle is called in ragged mode with the batch's max lengths so that it folds the window
+    # like the batched call does (flash_api.cpp:515-516 uses max_seqlen_k: 1024 < 8192 stays a
+    # local window even for the 513-token sequence, which selects the -slope*|i-j| ALiBi form and
+    # with it the LSE convention).
+    mx = max(lens)
+
+    def oracle_seq(qs, ks, vs, sl, n):
+        c = np.array([0, n], np.int32)
+        return fa_oracle.attention_fwd(f(qs), f(ks), f(vs), dtype="bf16", causal=True, window=(1024, 0),
+                                       alibi_slopes=f(sl), cu_seqlens_q=c, cu_seqlens_k=c,
+                                       max_seqlen_q=mx, max_seqlen_k=mx)
+
+    # short sequences, all heads (<= 1024 tokens in total per call)
+    for i in (6, 7):
+        a, e = cuh[i], cuh[i + 1]
+        ro, rl = oracle_seq(q[a:e], k[a:e], v[a:e], slopes[i:i + 1], lens[i])
+        assert np.abs(f(out[a:e]) - ro).max() <= ulp_tol("bf16", ro)
+        assert np.abs(f(lse[i, :, :lens[i]]) - rl[0, :, :lens[i]]).max() <= 2e-3
+        alone, lse1 = _cabi().fwd(q[a:e], k[a:e], v[a:e], cu_seqlens_q=_cu([lens[i]]), cu_seqlens_k=_cu([lens[i]]),
+                                  max_seqlen_q=mx, max_seqlen_k=mx, causal=True, window=(1024, 0),
+                                  alibi_slopes=slopes[i:i + 1].contiguous())
+        assert torch.equal(alone, out[a:e])
+    # one query head of the two longest sequences (true sliding window: 1024 < seqlen)
+    for i, hq in ((0, 5), (1, 30)):
+        a, e = cuh[i], cuh[i + 1]
+        kvh = hq // (h // hk)
+        ro, rl = oracle_seq(q[a:e, hq:hq + 1], k[a:e, kvh:kvh + 1], v[a:e, kvh:kvh + 1],
+                            slopes[i:i + 1, hq:hq + 1], lens[i])
+        assert np.abs(f(out[a:e, hq:hq + 1]) - ro).max() <= ulp_tol("bf16", ro)
+        assert np.abs(f(lse[i, hq:hq + 1, :lens[i]]) - rl[0, :, :lens[i]]).max() <= 2e-3
