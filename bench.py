@@ -118,6 +118,18 @@ def aggregate(work_per_rank_step, steps, world, elapsed_max, scale):
     return work_per_rank_step * steps * world / elapsed_max / scale
 
 
+def pmc_traffic(workload, kernels):
+    """HBM bytes per launch of the named kernel(s), from the committed PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected with rocprofv3 in runs of their own, never inside a timed run); None
+    when no pass exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        table = json.load(open(path)).get(workload.replace("_fwd", ""), {})
+        return sum(table[k]["hbm_bytes"] for k in kernels.split("+")) if table else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def fwd_flops(b, sq, sk, h, d, causal):
     f = 4.0 * b * h * sq * sk * d
     return f / 2 if causal else f
@@ -342,7 +354,8 @@ def main():
         avg = sum(durs) / len(durs)
         achieved = kwork / (avg * 1e-3) / scale
         roof = {"bound": bound, "kernel": kern_name, "achieved": achieved, "peak": peak,
-                "unit": unit, "frac": achieved / peak, "avg_kernel_ms": avg, "traffic": None}
+                "unit": unit, "frac": achieved / peak, "avg_kernel_ms": avg,
+                "traffic": pmc_traffic(args.workload, kern_name)}
 
     # ---- torch SDPA on the same GPU and inputs (rank 0) ----
     if rank == 0 and not args.no_sdpa and mode in ("fwd", "fwd_bwd"):
