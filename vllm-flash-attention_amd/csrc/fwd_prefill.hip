@@ -15,6 +15,7 @@
 //   * masks (causal / sliding window / key tail) and ALiBi are applied in registers, only on
 //     tiles that need them (wave-uniform test).
 #include "vfa_kernel_params.h"
+#include <type_traits>
 
 namespace vfa {
 
@@ -141,16 +142,22 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             vreg[i] = ok ? *(const i32x4 *)(vg + vo + ch * 8) : i32x4{0, 0, 0, 0};
         }
     };
-    auto store_tile = [&](int buf) {
-        char *kb = smem + buf * Cfg::TILE_BYTES;
-        char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+    // LDS byte offsets are loop invariant per lane: computing the XOR swizzle inside the tile loop
+    // costs more VALU issue slots than the softmax itself, so they are built once here and the
+    // tile loop is unrolled by two, which makes the buffer / k-step / key-block parts compile-time
+    // constants that fold into the DS instructions' immediate offset field.
+    int st_off[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int c = tid + i * NT;
+        st_off[i] = lds_off<DP>(c / CPR, c % CPR);
+    }
+    auto store_tile = [&](auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
 #pragma unroll
         for (int i = 0; i < CH; i++) {
-            const int c = tid + i * NT;
-            const int row = c / CPR, ch = c % CPR;
-            const int off = lds_off<DP>(row, ch);
-            *(i32x4 *)(kb + off) = kreg[i];
-            *(i32x4 *)(vb + off) = vreg[i];
+            *(i32x4 *)(smem + st_off[i] + BUF * Cfg::TILE_BYTES) = kreg[i];
+            *(i32x4 *)(smem + st_off[i] + (2 + BUF) * Cfg::TILE_BYTES) = vreg[i];
         }
     };
 
@@ -180,20 +187,31 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
     const float c2 = p.scale_log2;
 
-    // per-lane address pieces for the transposed V reads
+    // per-lane LDS read offsets (see the note at st_off)
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+    int k_rd[KS];        // K row read of k-step ks: row r (+32 per key block), chunk 2 ks + hh
+    int v_rd[NDB][2];    // V transposed read of d block db: rows 4 hh + tr_q (+8), +16 per k-step
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) k_rd[ks] = lds_off<DP>(r, 2 * ks + hh);
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            v_rd[db][e] = lds_off<DP>(4 * hh + tr_q + 8 * e, 4 * db + 2 * tr_g + (tr_p >> 1)) + 8 * (tr_p & 1);
+    constexpr int ROWB = DP * 2;
 
     load_tile(n_max - 1);
-    store_tile(0);
+    store_tile(std::integral_constant<int, 0>{});
     __syncthreads();
 
-    int buf = 0;
-    for (int n = n_max - 1; n >= n_min; n--) {
+    // one K/V tile; BUF (compile time) is the LDS buffer it sits in
+    auto tile_step = [&](const int n, auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
         const bool has_next = n > n_min;
         if (has_next) load_tile(n - 1);
 
-        const char *kb = smem + buf * Cfg::TILE_BYTES;
-        const char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
+        const char *kb = smem + BUF * Cfg::TILE_BYTES;
+        const char *vb = smem + (2 + BUF) * Cfg::TILE_BYTES;
         const int c0 = n * BN;
         // The tile range [n_min, n_max) is the block's; a wave whose 32 rows see none of this
         // tile's keys (above its own diagonal, or left of its window) only helps with the staging.
@@ -207,12 +225,11 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         f32x16 s[2];
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; kb2++) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) s[kb2][j] = 0.f;
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-                const i32x4 kf = *(const i32x4 *)(kb + lds_off<DP>(32 * kb2 + r, 2 * ks + hh));
-                s[kb2] = mma32<BF16>(kf, qf[ks], s[kb2]);
+                const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks] + 32 * kb2 * ROWB);
+                s[kb2] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[kb2]);
             }
         }
 
@@ -281,10 +298,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         for (int db = 0; db < NDB; db++) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                const int row0 = 16 * ks + 4 * hh + tr_q;
-                const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
-                const s16x4 v0 = lds_read_tr16(vb + lds_off<DP>(row0, ch) + 8 * (tr_p & 1));
-                const s16x4 v1 = lds_read_tr16(vb + lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1));
+                const s16x4 v0 = lds_read_tr16(vb + v_rd[db][0] + 16 * ks * ROWB);
+                const s16x4 v1 = lds_read_tr16(vb + v_rd[db][1] + 16 * ks * ROWB);
                 i32x4 vf;
                 const i32x2 a0 = __builtin_bit_cast(i32x2, v0), a1 = __builtin_bit_cast(i32x2, v1);
                 vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a1[0]; vf[3] = a1[1];
@@ -293,9 +308,15 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         }
         }  // !skip
 
-        if (has_next) store_tile(buf ^ 1);
+        if (has_next) store_tile(std::integral_constant<int, BUF ^ 1>{});
         __syncthreads();
-        buf ^= 1;
+    };
+
+    for (int n = n_max - 1;;) {
+        tile_step(n, std::integral_constant<int, 0>{});
+        if (--n < n_min) break;
+        tile_step(n, std::integral_constant<int, 1>{});
+        if (--n < n_min) break;
     }
 
     // ---- epilogue: normalise, LSE (softmax.h:168-185), store O through LDS as whole rows ----
