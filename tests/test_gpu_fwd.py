@@ -385,3 +385,55 @@ def test_config4_varlen_gqa_window_alibi():
                             slopes[i:i + 1, hq:hq + 1], lens[i])
         assert np.abs(f(out[a:e, hq:hq + 1]) - ro).max() <= ulp_tol("bf16", ro)
         assert np.abs(f(lse[i, hq:hq + 1, :lens[i]]) - rl[0, :, :lens[i]]).max() <= 2e-3
+
+
+def test_varlen_single_token_gqa_fold_and_empty_sequences():
+    """varlen_fwd with max_seqlen_q == 1 and GQA takes the head-folding path of
+    flash_api.cpp:500-507 (dense query, ragged keys); also a batch with an empty key sequence
+    (output 0, LSE +inf for it) and an empty query sequence."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(5)
+    b, h, hk, d = 4, 8, 2, 128
+    kl = [300, 17, 1000, 64]
+    q = torch.randn(b, h, d, device="cuda", dtype=torch.float16)
+    k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.float16)
+    v = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.float16)
+    cq, ck = _cu([1] * b), _cu(kl)
+    out, lse, _ = fa.flash_attn_varlen_func(q, k, v, cq, ck, 1, max(kl), causal=True, return_attn_probs=True)
+    f = lambda t: t.float().cpu().numpy()
+    ro, rl = fa_oracle.attention_fwd(f(q), f(k), f(v), dtype="fp16", causal=True, cu_seqlens_q=cq.cpu().numpy(),
+                                     cu_seqlens_k=ck.cpu().numpy(), max_seqlen_q=1, max_seqlen_k=max(kl))
+    assert out.shape == q.shape and lse.shape == (b, h, 1)
+    assert np.abs(f(out) - ro).max() <= ulp_tol("fp16", ro)
+    assert np.abs(f(lse) - rl).max() <= 1e-3
+    # ragged batch with an empty key sequence and an empty query sequence
+    ql, kl = [5, 0, 40], [0, 30, 40]
+    q = torch.randn(sum(ql), 2, 64, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(kl), 2, 64, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(sum(kl), 2, 64, device="cuda", dtype=torch.bfloat16)
+    out, lse = _cabi().fwd(q, k, v, cu_seqlens_q=_cu(ql), cu_seqlens_k=_cu(kl), max_seqlen_q=40, max_seqlen_k=40)
+    assert torch.equal(out[:5], torch.zeros_like(out[:5]))
+    assert torch.isposinf(lse[0, :, :5]).all()
+    ro, rl = fa_oracle.attention_fwd(f(q), f(k), f(v), dtype="bf16", cu_seqlens_q=_cu(ql).cpu().numpy(),
+                                     cu_seqlens_k=_cu(kl).cpu().numpy(), max_seqlen_q=40, max_seqlen_k=40)
+    assert np.abs(f(out) - ro).max() <= ulp_tol("bf16", ro)
+
+
+def test_kvcache_without_seqlens_and_seqlen_k_zero():
+    import vllm_flash_attn as fa
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    torch.manual_seed(6)
+    q = torch.randn(2, 3, 4, 64, device="cuda", dtype=torch.float16)
+    kc = torch.randn(2, 100, 4, 64, device="cuda", dtype=torch.float16)
+    vc = torch.randn(2, 100, 4, 64, device="cuda", dtype=torch.float16)
+    out = fa.flash_attn_with_kvcache(q, kc, vc, causal=True)   # whole cache is valid
+    f = lambda t: t.float().cpu().numpy()
+    ro, _ = fa_oracle.attention_fwd(f(q), f(kc), f(vc), dtype="fp16", causal=True)
+    assert np.abs(f(out) - ro).max() <= ulp_tol("fp16", ro)
+    # seqlen_k == 0: flash_api.cpp:401-405
+    k0 = torch.empty(2, 0, 4, 64, device="cuda", dtype=torch.float16)
+    o0, l0, _ = fa.flash_attn_func(q, k0, k0, return_attn_probs=True)
+    assert torch.equal(o0, torch.zeros_like(o0)) and torch.isposinf(l0).all()
