@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
-HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip"]
+HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_prefill_w64.hip", "fwd_splitkv.hip", "bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
 

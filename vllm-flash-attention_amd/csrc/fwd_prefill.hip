@@ -16,8 +16,25 @@
 //     tiles that need them (wave-uniform test).
 #include "vfa_kernel_params.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace vfa {
+
+#ifdef VFA_STAMP
+// Diagnostic build only: per-phase shader-clock sums of the tile loop (never in the product build).
+__device__ unsigned long long g_stamps[4096 * 8];
+#define STAMP(slot)                                                        \
+    do {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        unsigned long long t_;                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        acc_[slot] += t_ - last_;                                          \
+        last_ = t_;                                                        \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 
 constexpr int BN = 64;
 
@@ -204,11 +221,18 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     store_tile(std::integral_constant<int, 0>{});
     __syncthreads();
 
+#ifdef VFA_STAMP
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+    const unsigned long long t_begin_ = last_;
+#endif
     // one K/V tile; BUF (compile time) is the LDS buffer it sits in
     auto tile_step = [&](const int n, auto BUFC) {
         constexpr int BUF = decltype(BUFC)::value;
         const bool has_next = n > n_min;
+        STAMP(7);
         if (has_next) load_tile(n - 1);
+        STAMP(0);
 
         const char *kb = smem + BUF * Cfg::TILE_BYTES;
         const char *vb = smem + (2 + BUF) * Cfg::TILE_BYTES;
@@ -233,6 +257,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             }
         }
 
+        STAMP(1);
         // ---- masks and ALiBi, only where needed (mask.h:128-209) ----
         bool need = has_alibi || (c0 + BN > sk);
         if (p.is_causal || p.is_local) need = need || (c0 + BN > q0w + 1 + sk - sq + p.wr);
@@ -284,6 +309,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             }
         l_run += psum;
 
+        STAMP(2);
         // ---- O^T += V^T P^T.  P fragment of k-step ks (16 keys) = regs 8(ks&1).. of s[ks>>1];
         // element j of lane half hh is key 16 ks + 8 (j>>2) + 4 hh + (j&3). ----
         i32x4 pf[4];
@@ -306,10 +332,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 o[db] = mma32<BF16>(vf, pf[ks], o[db]);
             }
         }
+        STAMP(3);
         }  // !skip
 
         if (has_next) store_tile(std::integral_constant<int, BUF ^ 1>{});
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
     };
 
     for (int n = n_max - 1;;) {
@@ -319,6 +348,14 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         if (--n < n_min) break;
     }
 
+#ifdef VFA_STAMP
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long *dst = g_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 6; i++) dst[i] = acc_[i];
+        dst[6] = last_ - t_begin_;
+        dst[7] = (unsigned long long)(n_max - n_min);
+    }
+#endif
     // ---- epilogue: normalise, LSE (softmax.h:168-185), store O through LDS as whole rows ----
     const float l_tot = half_swap_sum(l_run);
     const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
@@ -368,9 +405,19 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+bool fwd_prefill64_supported(const KParams &p);                  // fwd_prefill_w64.hip
+hipError_t run_fwd_prefill64(const KParams &p, hipStream_t stream);
+
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
+    {
+        static const int w64_min_q = [] {
+            const char *e = getenv("VFA_FWD_W64_MIN_Q");  // tuning override
+            return e ? atoi(e) : 1 << 30;
+        }();
+        if (p.seqlen_q >= w64_min_q && fwd_prefill64_supported(p)) return run_fwd_prefill64(p, stream);
+    }
     // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) wins once a block
     // walks many key tiles; below that two independent 4-wave blocks per CU overlap each other's
     // prologue / epilogue / barrier stalls better (measured on MI355X: +9..14 % at seqlen <= 2048,
@@ -388,3 +435,9 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
 }
 
 }  // namespace vfa
+
+#ifdef VFA_STAMP
+extern "C" int vfa_debug_read_stamps(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps), n * sizeof(unsigned long long));
+}
+#endif
