@@ -53,7 +53,11 @@ struct PrefillCfg {
     static_assert(TILE_CHUNKS % NT == 0, "tile must divide over threads");
 };
 
-template <int DP, bool BF16, int NW>
+// FAST: K/V are contiguous per (batch, head) (no block table) and fit a 32-bit byte offset, so
+// tiles are fetched with buffer loads whose descriptor ends at the last valid key row: the key
+// tail and the head-dim padding read as zeros without any predication or 64-bit address
+// arithmetic in the tile loop.
+template <int DP, bool BF16, int NW, bool FAST>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
@@ -137,7 +141,28 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     }
 
     i32x4 kreg[CH], vreg[CH];
+    // FAST path state: descriptors and the per-lane byte offset of chunk 0 (out of range for the
+    // head-dim padding columns, so that they load zeros)
+    const unsigned k_bytes = FAST ? (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2) : 0u;
+    const unsigned v_bytes = FAST ? (unsigned)(((int64_t)(sk - 1) * p.v_rs + p.d) * 2) : 0u;
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)kg, 0, k_bytes, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vg, 0, v_bytes, 0x00020000);
+    const bool colok0 = (tid % CPR) * 8 < p.d;
+    const unsigned k_voff = colok0 ? (unsigned)(((tid / CPR) * (int)p.k_rs + (tid % CPR) * 8) * 2) : 0x80000000u;
+    const unsigned v_voff = colok0 ? (unsigned)(((tid / CPR) * (int)p.v_rs + (tid % CPR) * 8) * 2) : 0x80000000u;
+    const unsigned k_rs2 = (unsigned)p.k_rs * 2, v_rs2 = (unsigned)p.v_rs * 2;
     auto load_tile = [&](int n) {
+        if constexpr (FAST) {
+            constexpr int RSTEP = NT / CPR;  // rows between a lane's chunks
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                kreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    k_rsrc, k_voff + (unsigned)(n * BN + RSTEP * i) * k_rs2, 0, 0));
+                vreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    v_rsrc, v_voff + (unsigned)(n * BN + RSTEP * i) * v_rs2, 0, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int c = tid + i * NT;
@@ -196,7 +221,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     for (int i = 0; i < NDB; i++)
 #pragma unroll
         for (int j = 0; j < 16; j++) o[i][j] = 0.f;
-    float m_run = -INFINITY;  // running row max (raw score units), same in both lane halves
+    float m_run = -INFINITY;  // reference point of the exponentials (raw score units): the running
+                              // row max, followed lazily; same in both lane halves
     float l_run = 0.f;        // running row sum, PARTIAL per lane half
 
     float alibi = 0.f;
@@ -286,9 +312,15 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int j = 0; j < 16; j++) mx = fmaxf(mx, s[1][j]);
         mx = half_swap_max(mx);
-        const float m_new = fmaxf(m_run, mx);
+        // The reference point of the exponentials follows the running maximum lazily: it moves
+        // (for every row of the wave at once) only when some row's maximum outgrew it by more
+        // than 2^RESCALE_LOG2, so P stays below that bound and the rescale of O becomes rare.
+        // Any reference point gives the same O and LSE up to rounding.
+        constexpr float RESCALE_LOG2 = 4.f;
+        const bool upd = __any((mx - m_run) * c2 > RESCALE_LOG2);
+        const float m_new = upd ? fmaxf(m_run, mx) : m_run;
         const float m_cur = (m_new == -INFINITY) ? 0.f : m_new;
-        if (!__all(m_new == m_run)) {
+        if (upd) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_cur) * c2);
             l_run *= alpha;
 #pragma unroll
@@ -386,13 +418,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW>
-static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
+template <int DP, bool BF16, int NW, bool FAST>
+static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_prefill_kernel<DP, BF16, NW>;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW, FAST>;
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
@@ -403,6 +435,20 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p,
                        n_mblocks);
     return hipGetLastError();
+}
+
+// Contiguous K/V whose per-(batch, head) extent fits a 32-bit buffer offset take the buffer-load path.
+static bool kv_fits_buffer(const KParams &p) {
+    if (p.block_table) return false;
+    const int64_t lim = (int64_t)1 << 30;  // bytes, with room for the tile offsets added per lane
+    const int64_t rows = (int64_t)p.seqlen_k + 256;
+    return rows * p.k_rs * 2 < lim && rows * p.v_rs * 2 < lim;
+}
+
+template <int DP, bool BF16, int NW>
+static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
+    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, NW, true>(p, stream)
+                             : launch_prefill_impl<DP, BF16, NW, false>(p, stream);
 }
 
 bool fwd_prefill64_supported(const KParams &p);                  // fwd_prefill_w64.hip
