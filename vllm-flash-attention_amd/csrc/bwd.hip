@@ -90,7 +90,7 @@ struct BwdCfg {
     static constexpr int QCH = (BW_QM * CPR + NT - 1) / NT;   // chunks per thread per Q (or dO) slice
 };
 
-template <int DP, bool BF16, int NW>
+template <int DP, bool BF16, int NW, bool FAST>
 __global__ void __launch_bounds__(NW * 64, 1)
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
@@ -186,10 +186,34 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // query slices are swept from the last one down: under a causal mask every key block sees the
     // last rows, so the co-resident blocks of a pair read the same slice at about the same time
     auto m_of = [&](int step) { return m_max - 1 - step % n_steps_per_head; };
+    // FAST: Q / dO rows come through buffer loads whose descriptor (rebuilt per head, it is four
+    // scalar words) ends at the last valid query row, so the row tail and the head-dim padding
+    // read as zeros with no predication and no 64-bit address arithmetic per chunk.
+    unsigned q_voff[QCH], do_voff[QCH];
+#pragma unroll
+    for (int i = 0; i < QCH; i++) {
+        const int c = tid + i * NT;
+        const int row = c / CPR, ch = c % CPR;
+        const bool ok = c < BW_QM * CPR && ch * 8 < p.d;
+        q_voff[i] = ok ? (unsigned)((row * (int)p.q_rs + ch * 8) * 2) : 0x80000000u;
+        do_voff[i] = ok ? (unsigned)((row * (int)p.do_rs + ch * 8) * 2) : 0x80000000u;
+    }
     auto load_slice = [&](int step) {
         const int bidh = head_of(step), q0 = m_of(step) * BW_QM;
         const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
         const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
+        if constexpr (FAST) {
+            const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)qg, 0, (unsigned)(((int64_t)(sq - 1) * p.q_rs + p.d) * 2), 0x00020000);
+            const auto do_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)dog, 0, (unsigned)(((int64_t)(sq - 1) * p.do_rs + p.d) * 2), 0x00020000);
+            const unsigned q_t = (unsigned)q0 * (unsigned)p.q_rs * 2, do_t = (unsigned)q0 * (unsigned)p.do_rs * 2;
+#pragma unroll
+            for (int i = 0; i < QCH; i++) {
+                qreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, q_voff[i] + q_t, 0, 0));
+                doreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(do_rsrc, do_voff[i] + do_t, 0, 0));
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < QCH; i++) {
             const int c = tid + i * NT;
@@ -197,6 +221,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const bool ok = c < BW_QM * CPR && (q0 + row) < sq && ch * 8 < p.d;
             qreg[i] = ok ? *(const i32x4 *)(qg + (int64_t)(q0 + row) * p.q_rs + ch * 8) : i32x4{0, 0, 0, 0};
             doreg[i] = ok ? *(const i32x4 *)(dog + (int64_t)(q0 + row) * p.do_rs + ch * 8) : i32x4{0, 0, 0, 0};
+        }
         }
         if (tid < 64) {
             const int row = q0 + (tid & 31);
@@ -366,19 +391,33 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW>
-static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
+// Per-(batch) extents that fit a 32-bit byte offset (with room for the tile offsets) take the
+// buffer-load paths of the kernels below.
+static bool bwd_fits_buffer(const KParams &p) {
+    const int64_t lim = (int64_t)1 << 30;
+    const int64_t rq = (int64_t)p.seqlen_q + 256, rk = (int64_t)p.seqlen_k + 256;
+    return rq * p.q_rs * 2 < lim && rq * p.do_rs * 2 < lim && rk * p.k_rs * 2 < lim && rk * p.v_rs * 2 < lim;
+}
+
+template <int DP, bool BF16, int NW, bool FAST>
+static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
     using Cfg = BwdCfg<DP, NW>;
     const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dkdv_kernel<DP, BF16, NW>;
+    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST>;
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_kblocks);
     return hipGetLastError();
+}
+
+template <int DP, bool BF16, int NW>
+static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
+    return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
+                              : launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,7 +437,7 @@ struct DqCfg {
     static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
 };
 
-template <int DP, bool BF16, int NW>
+template <int DP, bool BF16, int NW, bool FAST>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 bwd_dq_kernel(const KParams p, const int n_mblocks) {
     using Cfg = DqCfg<DP, NW>;
@@ -459,7 +498,27 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
         const unsigned short *kg = (const unsigned short *)p.k + bi.k_off(p.k_bs, p.k_rs, bidb) + (int64_t)hk * p.k_hs;
         const unsigned short *vg = (const unsigned short *)p.v + bi.k_off(p.v_bs, p.v_rs, bidb) + (int64_t)hk * p.v_hs;
         i32x4 kreg[CH], vreg[CH];
+        // FAST: as in the forward kernel, K / V tiles through buffer loads bounded at the last key row
+        const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)kg, 0, FAST ? (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2) : 0u, 0x00020000);
+        const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)vg, 0, FAST ? (unsigned)(((int64_t)(sk - 1) * p.v_rs + p.d) * 2) : 0u, 0x00020000);
+        const bool colok0 = (tid % CPR) * 8 < p.d;
+        const unsigned k_voff = colok0 ? (unsigned)(((tid / CPR) * (int)p.k_rs + (tid % CPR) * 8) * 2) : 0x80000000u;
+        const unsigned v_voff = colok0 ? (unsigned)(((tid / CPR) * (int)p.v_rs + (tid % CPR) * 8) * 2) : 0x80000000u;
+        const unsigned k_rs2 = (unsigned)p.k_rs * 2, v_rs2 = (unsigned)p.v_rs * 2;
         auto load_tile = [&](int n) {
+            if constexpr (FAST) {
+                constexpr int RSTEP = NT / CPR;
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    kreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        k_rsrc, k_voff + (unsigned)(n * DQ_BN + RSTEP * i) * k_rs2, 0, 0));
+                    vreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        v_rsrc, v_voff + (unsigned)(n * DQ_BN + RSTEP * i) * v_rs2, 0, 0));
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 const int c = tid + i * NT;
@@ -609,19 +668,25 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW>
-static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
+template <int DP, bool BF16, int NW, bool FAST>
+static hipError_t launch_dq_impl(const KParams &p, hipStream_t stream) {
     using Cfg = DqCfg<DP, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dq_kernel<DP, BF16, NW>;
+    auto kern = bwd_dq_kernel<DP, BF16, NW, FAST>;
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
     return hipGetLastError();
+}
+
+template <int DP, bool BF16, int NW>
+static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
+    return bwd_fits_buffer(p) ? launch_dq_impl<DP, BF16, NW, true>(p, stream)
+                              : launch_dq_impl<DP, BF16, NW, false>(p, stream);
 }
 
 template <int DP, bool BF16>
