@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle shares of the forward tile loop (needs libvfa_hip_stamp.so built with -DVFA_STAMP)."""
+"""Diagnostic: per-phase cycle shares of the forward tile loop.
+Build the stamped library first: python vllm-flash-attention_amd/build.py --stamp"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):

@@ -8,6 +8,8 @@
 
 The counterpart of the reference's setup.py:134-219 (CUDAExtension "vllm_flash_attn_2_cuda").
 Usage: python build.py [--force] [--no-torch-ext]
+       python build.py --stamp     diagnostic libvfa_hip_stamp.so (-DVFA_STAMP: per-phase cycle
+                                   counters in the forward tile loop, read by tools/stamp_fwd.py)
 """
 import os
 import subprocess
@@ -20,7 +22,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
-HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_prefill_w64.hip", "fwd_splitkv.hip", "bwd.hip"]
+HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
 
@@ -56,6 +58,20 @@ def build_hip(force=False):
     if force or jobs or _newer(LIB, objs):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
+
+
+def build_stamp():
+    """Diagnostic variant of the library with in-kernel phase stamps (never loaded by the product)."""
+    out = os.path.join(HERE, "libvfa_hip_stamp.so")
+    od = os.path.join(OBJ, "stamp")
+    os.makedirs(od, exist_ok=True)
+    objs = []
+    for src in HIP_SOURCES:
+        o = os.path.join(od, src.replace(".hip", ".o"))
+        subprocess.check_call([HIPCC] + HIP_FLAGS + ["-DVFA_STAMP", "-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 def torch_ext_path():
@@ -99,5 +115,8 @@ def build_all(force=False, torch_ext=True):
 
 
 if __name__ == "__main__":
+    if "--stamp" in sys.argv:
+        print(build_stamp())
+        sys.exit(0)
     force = "--force" in sys.argv
     print(build_all(force, "--no-torch-ext" not in sys.argv))

@@ -16,7 +16,6 @@
 //     tiles that need them (wave-uniform test).
 #include "vfa_kernel_params.h"
 #include <type_traits>
-#include <cstdlib>
 
 namespace vfa {
 
@@ -330,16 +329,16 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         }
         m_run = m_new;
         const float mc = m_cur * c2;
-        float psum = 0.f;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};  // four short chains instead of one of 32 dependent adds
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; kb2++)
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb2][j], c2, -mc));
                 s[kb2][j] = e;
-                psum += e;
+                ps[j & 3] += e;
             }
-        l_run += psum;
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
         STAMP(2);
         // ---- O^T += V^T P^T.  P fragment of k-step ks (16 keys) = regs 8(ks&1).. of s[ks>>1];
@@ -451,19 +450,9 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
                              : launch_prefill_impl<DP, BF16, NW, false>(p, stream);
 }
 
-bool fwd_prefill64_supported(const KParams &p);                  // fwd_prefill_w64.hip
-hipError_t run_fwd_prefill64(const KParams &p, hipStream_t stream);
-
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
-    {
-        static const int w64_min_q = [] {
-            const char *e = getenv("VFA_FWD_W64_MIN_Q");  // tuning override
-            return e ? atoi(e) : 1 << 30;
-        }();
-        if (p.seqlen_q >= w64_min_q && fwd_prefill64_supported(p)) return run_fwd_prefill64(p, stream);
-    }
     // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) wins once a block
     // walks many key tiles; below that two independent 4-wave blocks per CU overlap each other's
     // prologue / epilogue / barrier stalls better (measured on MI355X: +9..14 % at seqlen <= 2048,
