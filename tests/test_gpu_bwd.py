@@ -133,7 +133,7 @@ def test_bwd_noncontiguous_dout_and_packed():
     out2 = fa.flash_attn_func(q, k, v, causal=True)
     dq, dk, dv = torch.autograd.grad(out2, (q, k, v), g.contiguous())
     assert torch.equal(dqkv[:, :, 1], dk) and torch.equal(dqkv[:, :, 2], dv)
-    assert (dqkv[:, :, 0].float() - dq.float()).abs().max().item() <= 2e-3  # dq: atomic order
+    assert torch.equal(dqkv[:, :, 0], dq)  # no atomics anywhere: dq is bitwise reproducible too
     kv = torch.stack([k.detach(), v.detach()], dim=2).requires_grad_()
     out3 = fa.flash_attn_kvpacked_func(q.detach().requires_grad_(), kv, causal=True)
     (dkv,) = torch.autograd.grad(out3, kv, g)
@@ -141,8 +141,8 @@ def test_bwd_noncontiguous_dout_and_packed():
 
 
 def test_bwd_dk_dv_repeatable_and_no_nan_on_literal_varlen():
-    """dk / dv are summed in registers in a fixed order: bitwise repeatable.  dq uses fp32 atomics:
-    equal to rounding.  Literal cu_seqlens of tests/test_flash_attn.py:2291-2316: no NaN."""
+    """dq / dk / dv are all summed in registers in a fixed order (no atomics): bitwise repeatable.
+    Literal cu_seqlens of tests/test_flash_attn.py:2291-2316: no NaN."""
     import cabi
     torch.manual_seed(2)
     for cu in ([0, 76, 110, 256], [0, 1, 2, 3]):
@@ -160,8 +160,7 @@ def test_bwd_dk_dv_repeatable_and_no_nan_on_literal_varlen():
             assert not torch.isnan(t).any()
         for _ in range(5):
             r1 = cabi.bwd(do, q, k, v, out, lse, **kw)
-            assert torch.equal(r0[1], r1[1]) and torch.equal(r0[2], r1[2])
-            assert (r0[0].float() - r1[0].float()).abs().max().item() <= 4e-3
+            assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1]) and torch.equal(r0[2], r1[2])
 
 
 def test_bwd_overflow_inputs():
@@ -182,3 +181,32 @@ def test_bwd_overflow_inputs():
         for a, r in ((dq, rdq), (dk, rdk), (dv, rdv)):
             assert torch.isfinite(a).all()
             assert np.abs(f(a) - r).max() <= 8 * 2.0 ** -11 * max(1.0, np.abs(r).max())
+
+
+def test_huge_row_stride_takes_the_generic_load_path():
+    """K / V whose rows are so far apart that a (batch, head) slice exceeds a 32-bit buffer
+    offset: forward and backward switch from buffer loads to plain global loads.  Both paths do the
+    same arithmetic, so the results must be bitwise those of the contiguous tensors."""
+    import cabi
+    torch.manual_seed(5)
+    b, sq, sk, h, hk, d = 1, 300, 700, 4, 2, 128
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn_like(q)
+    wide = 600 * 1024  # elements per row: (sk + 256) rows x 1.2 MB > 2^30 bytes
+    kbig = torch.empty(b, sk, wide, device="cuda", dtype=torch.bfloat16)
+    vbig = torch.empty(b, sk, wide, device="cuda", dtype=torch.bfloat16)
+    ks = kbig[:, :, : hk * d].view(b, sk, hk, d)
+    vs = vbig[:, :, : hk * d].view(b, sk, hk, d)
+    ks.copy_(k)
+    vs.copy_(v)
+    assert (sk + 256) * ks.stride(1) * 2 >= 1 << 30
+    for causal in (False, True):
+        out0, lse0 = cabi.fwd(q, k, v, causal=causal)[:2]
+        out1, lse1 = cabi.fwd(q, ks, vs, causal=causal)[:2]
+        assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+        g0 = cabi.bwd(do, q, k, v, out0, lse0, causal=causal)
+        g1 = cabi.bwd(do, q, ks, vs, out0, lse0, causal=causal)
+        for a, c in zip(g0[:3], g1[:3]):
+            assert torch.equal(a, c)

@@ -27,6 +27,22 @@
 
 namespace vfa {
 
+#ifdef VFA_STAMP
+// Diagnostic build only: per-phase shader-clock sums of the dK/dV step loop.
+__device__ unsigned long long g_stamps_dkdv[512 * 8 * 8];
+#define STAMP(slot)                                                        \
+    do {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        unsigned long long t_;                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        acc_[slot] += t_ - last_;                                          \
+        last_ = t_;                                                        \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 constexpr int BW_QM = 32;          // query rows per step
 
 template <bool BF16>
@@ -182,10 +198,16 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // ---- Q / dO slice staging (register prefetch, two LDS buffers) ----
     i32x4 qreg[QCH], doreg[QCH];
     float rowc = 0.f;  // lse (tid < 32) or delta (32 <= tid < 64) of the slice
-    auto head_of = [&](int step) { return hk * p.h_ratio + step / n_steps_per_head; };
-    // query slices are swept from the last one down: under a causal mask every key block sees the
-    // last rows, so the co-resident blocks of a pair read the same slice at about the same time
-    auto m_of = [&](int step) { return m_max - 1 - step % n_steps_per_head; };
+    // Step -> (query head of the GQA group, 32-row slice).  Slices are swept from the last one
+    // down: under a causal mask every key block sees the last rows, so the co-resident blocks of
+    // a pair read the same slice at about the same time.  Kept as counters (an integer division
+    // per step costs more scalar/vector instructions than the step's address arithmetic).
+    auto advance = [&](int &hh_, int &m_) {
+        if (--m_ < m_min) {
+            m_ = m_max - 1;
+            ++hh_;
+        }
+    };
     // FAST: Q / dO rows come through buffer loads whose descriptor (rebuilt per head, it is four
     // scalar words) ends at the last valid query row, so the row tail and the head-dim padding
     // read as zeros with no predication and no 64-bit address arithmetic per chunk.
@@ -198,8 +220,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         q_voff[i] = ok ? (unsigned)((row * (int)p.q_rs + ch * 8) * 2) : 0x80000000u;
         do_voff[i] = ok ? (unsigned)((row * (int)p.do_rs + ch * 8) * 2) : 0x80000000u;
     }
-    auto load_slice = [&](int step) {
-        const int bidh = head_of(step), q0 = m_of(step) * BW_QM;
+    auto load_slice = [&](const int gh, const int m) {
+        const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
         const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
         const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
         if constexpr (FAST) {
@@ -230,30 +252,39 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             else rowc = ok ? p.dsoftmax_sum[((int64_t)bidb * p.h + bidh) * p.seqlen_q_rounded + row] : 0.f;
         }
     };
+    int st_off[QCH];
+#pragma unroll
+    for (int i = 0; i < QCH; i++) st_off[i] = lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
     auto store_slice = [&](int buf) {
         char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
 #pragma unroll
         for (int i = 0; i < QCH; i++) {
-            const int c = tid + i * NT;
-            if (c < BW_QM * CPR) {
-                const int off = lds_off<DP>(c / CPR, c % CPR);
-                *(i32x4 *)(qb + off) = qreg[i];
-                *(i32x4 *)(qb + Cfg::QT_BYTES + off) = doreg[i];
+            if (tid + i * NT < BW_QM * CPR) {
+                *(i32x4 *)(qb + st_off[i]) = qreg[i];
+                *(i32x4 *)(qb + Cfg::QT_BYTES + st_off[i]) = doreg[i];
             }
         }
         if (tid < 64) ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = rowc;
     };
 
-    if (total_steps > 0) load_slice(0);
+    int cur_h = 0, cur_m = m_max - 1, nxt_h = 0, nxt_m = m_max - 1;
+    advance(nxt_h, nxt_m);
+    if (total_steps > 0) load_slice(cur_h, cur_m);
     __syncthreads();  // every wave has its fragments: the freed tile space becomes the Q buffers
     if (total_steps > 0) store_slice(0);
     __syncthreads();
 
+#ifdef VFA_STAMP
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
     int buf = 0;
     for (int step = 0; step < total_steps; step++) {
-        const int bidh = head_of(step), q0 = m_of(step) * BW_QM;
+        const int bidh = hk * p.h_ratio + cur_h, q0 = cur_m * BW_QM;
         const bool has_next = step + 1 < total_steps;
-        if (has_next) load_slice(step + 1);
+        STAMP(7);
+        if (has_next) load_slice(nxt_h, nxt_m);
+        STAMP(0);
 
         const char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
         const char *dob = qb + Cfg::QT_BYTES;
@@ -274,6 +305,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const i32x4 qa = *(const i32x4 *)(qb + lds_off<DP>(r, 2 * ks + hh));
             s = mma32<BF16>(qa, kf[ks], s);
         }
+        STAMP(1);
         // ---- P = exp2(S*c - LSE*log2e) under the forward's mask and bias ----
         {
             const int col = kw0 + r;
@@ -303,6 +335,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                     s[4 * g4 + t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[4 * g4 + t], c2, -ls[t] * (float)M_LOG2E));
             }
         }
+        STAMP(2);
         // ---- dP'[q][key] = dO V^T - delta[q];  dS = P * dP' ----
         f32x16 dp;
 #pragma unroll
@@ -319,6 +352,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             else vb = vf[ks];
             dp = mma32<BF16>(da, vb, dp);
         }
+        STAMP(3);
         // 16-bit B operands: k-step ks2 (16 query rows) = regs 8 ks2 .. 8 ks2 + 7
         i32x4 pf[2], dsf[2];
 #pragma unroll
@@ -349,12 +383,25 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                 dk[db] = mma32<BF16>(qt, dsf[ks2], dk[db]);
             }
         }
+        STAMP(4);
         }  // !skip
 
         if (has_next) store_slice(buf ^ 1);
+        STAMP(5);
         __syncthreads();
+        STAMP(6);
         buf ^= 1;
+        cur_h = nxt_h;
+        cur_m = nxt_m;
+        advance(nxt_h, nxt_m);
     }
+#ifdef VFA_STAMP
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long *dst = g_stamps_dkdv + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 7; i++) dst[i] = acc_[i];
+        dst[7] = (unsigned long long)total_steps;
+    }
+#endif
 
     // ---- write dK (scaled) and dV for this wave's 32 keys, through LDS as whole rows ----
     __syncthreads();
@@ -720,3 +767,9 @@ hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
 }
 
 }  // namespace vfa
+
+#ifdef VFA_STAMP
+extern "C" int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_dkdv), n * sizeof(unsigned long long));
+}
+#endif
