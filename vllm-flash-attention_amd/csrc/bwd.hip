@@ -750,7 +750,11 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[2], stream);
     {
-        const bool big = p.seqlen_q > 128;
+        // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU: measured
+        // on MI355X, 4 waves win under a causal / window mask up to seqlen 2048 (d = 128) or 4096
+        // (d = 64) by 3..25 %, and without a mask below seqlen 2048; 8 waves win by 3..7 % beyond.
+        const bool masked = p.is_causal || p.is_local;
+        const bool big = masked ? p.seqlen_q >= (DP == 64 ? 8192 : 4096) : p.seqlen_q >= 2048;
         if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;

@@ -453,13 +453,15 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
-    // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) wins once a block
-    // walks many key tiles; below that two independent 4-wave blocks per CU overlap each other's
-    // prologue / epilogue / barrier stalls better (measured on MI355X: +9..14 % at seqlen <= 2048,
-    // -9 % at 8192).
-    const bool big = p.seqlen_q >= 4096;
+    // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) against two
+    // independent 4-wave blocks per CU, which overlap each other's prologue / epilogue / barrier
+    // stalls and split a causal diagonal more finely.  Measured on MI355X (bf16, 16k..64k tokens,
+    // seqlen 1k..16k): d = 64 is faster with 4 waves everywhere (+8..40 %); d = 128 without a mask
+    // is faster with 8 waves everywhere measured (+3..9 %); d = 128 causal / windowed crosses over
+    // between seqlen 4096 (equal) and 8192 (+8 % for 8 waves).
+    const bool masked = p.is_causal || p.is_local;
+    const bool big = masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 1024;
     if (p.d <= 64) {
-        if (big) return bf ? launch_prefill<64, true, 8>(p, stream) : launch_prefill<64, false, 8>(p, stream);
         return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
     } else if (p.d <= 128) {
         if (big) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
