@@ -166,7 +166,7 @@ def cpu_baseline(name, b, sq, sk, h, hk, d, dtype, causal, mode):
     from oracle import fa_oracle
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     threads = max(1, min(threads, 16))
-    hs = threads
+    hs = 3 * threads  # three heads per thread: about 10 s of CPU work for the headline shape
     rng = np.random.default_rng(0)
     s_q = sq if mode != "decode" else 1
     if mode == "decode":
@@ -194,6 +194,35 @@ def cpu_baseline(name, b, sq, sk, h, hk, d, dtype, causal, mode):
     dt = time.perf_counter() - t0
     return {"value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
             "sample": f"oracle {mode}, batch 1 x {hs} heads of {b} x {h} (full seqlen {sq}), {dt:.1f} s"}
+
+
+def cpu_sdpa(b, sq, sk, h, d, causal, mode):
+    """torch's CPU scaled_dot_product_attention (the other CPU reference the metric names) on the
+    same bounded sample shape as cpu_baseline: batch 1, as many heads as threads, full seqlen,
+    fp32 and bf16; forward or forward + autograd backward."""
+    import torch
+    import torch.nn.functional as F
+    if mode not in ("fwd", "fwd_bwd"):
+        return None
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = max(1, min(threads, 16))
+    torch.set_num_threads(threads)
+    res = {"cores": threads, "unit": "TFLOP/s",
+           "sample": f"torch CPU SDPA {mode}, batch 1 x {threads} heads (full seqlen {sq}), 1 warm-up + best of 2"}
+    flops = fwd_flops(1, sq, sk, threads, d, causal) * (3.5 if mode == "fwd_bwd" else 1.0)
+    for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        g = torch.Generator().manual_seed(0)
+        q, k, v = (torch.randn(1, threads, n, d, generator=g).to(dt_).requires_grad_(mode == "fwd_bwd")
+                   for n in (sq, sk, sk))
+        ts = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
+            if mode == "fwd_bwd":
+                torch.autograd.grad(o, (q, k, v), torch.ones_like(o))
+            ts.append(time.perf_counter() - t0)
+        res[name] = flops / min(ts[1:]) / 1e12
+    return res
 
 
 def main():
@@ -393,6 +422,9 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, b, sq, sk, h, hk, d, dtype, causal, mode)
+            sd = cpu_sdpa(b, sq, sk, h, d, causal, mode)
+            if sd:
+                line["cpu_sdpa"] = sd
         line.update(extra)
         print(json.dumps(line), flush=True)
     if dist is not None:

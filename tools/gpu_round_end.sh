@@ -22,6 +22,8 @@ for w in c3 c5; do
     timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$w/$c -o p -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa > $O/pmc_${w}_$c.log 2>&1
   done
 done
+# matrix-pipe busy share of the headline kernels (one pass: 2 SQ + 1 GRBM counter)
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_c3/MFMA -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa > $O/pmc_c3_MFMA.log 2>&1
 echo pmc done
 python tools/pmc_summarize.py $O/pmc_traffic.json c3=$O/pmc_c3 c5=$O/pmc_c5
 find $O -name "*kernel_stats.csv" | head

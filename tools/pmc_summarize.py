@@ -21,12 +21,20 @@ def collect(d):
                 a[1].add(row["Dispatch_Id"])
     out = {}
     for k, cs in acc.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
+            n = max(1, len(cs["GRBM_GUI_ACTIVE"][1]))
+            mf, gui = cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / n, cs["GRBM_GUI_ACTIVE"][0] / n
+            out.setdefault(k, {})["mfma"] = {
+                "sq_valu_mfma_busy_cycles": mf, "grbm_gui_active": gui,
+                "sq_busy_cycles": cs.get("SQ_BUSY_CYCLES", [0.0])[0] / n,
+                # busy cycles are summed over the chip's 1024 SIMDs (256 CUs x 4)
+                "mfma_busy_frac": mf / (gui * 1024.0) if gui else None}
         if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
             continue
         f = cs["FETCH_SIZE"][0] / max(1, len(cs["FETCH_SIZE"][1]))
         w = cs["WRITE_SIZE"][0] / max(1, len(cs["WRITE_SIZE"][1]))
-        out[k] = {"fetch_size_kb_raw": f, "read_bytes": f * 1024 * 2, "write_size_kb_raw": w,
-                  "write_bytes": w * 1024, "hbm_bytes": f * 2048 + w * 1024}
+        out.setdefault(k, {}).update({"fetch_size_kb_raw": f, "read_bytes": f * 1024 * 2, "write_size_kb_raw": w,
+                  "write_bytes": w * 1024, "hbm_bytes": f * 2048 + w * 1024})
     return out
 
 

@@ -43,7 +43,8 @@ __device__ unsigned long long g_stamps_dkdv[512 * 8 * 8];
 #define STAMP(slot) do { } while (0)
 #endif
 
-constexpr int BW_QM = 32;          // query rows per step
+// Query rows per step of the dK/dV kernel: sub-blocks of 32 rows, QSUB of them per staged slice
+// (one barrier and one load/store round per slice, so a taller slice amortises them).
 
 template <bool BF16>
 __global__ void __launch_bounds__(256)
@@ -88,8 +89,12 @@ struct BwdCfg {
     static constexpr bool V_IN_LDS = NW == 8;
     static constexpr int CPR = DP / 8;
     static constexpr int KV_BYTES = KB * DP * 2;              // one of K / V
-    static constexpr int QT_BYTES = BW_QM * DP * 2;           // one of Q / dO slice
-    static constexpr int QBUF_BYTES = 2 * QT_BYTES + 256;     // Q, dO, lse[32], delta[32]
+    // Two sub-blocks at d = 64 (measured +29 % on MI355X); at d = 128 the taller slice costs the
+    // registers the 8-wave kernel does not have (spills, -14 %).
+    static constexpr int QSUB = (NW == 8 && DP == 64) ? 2 : 1;
+    static constexpr int QM = 32 * QSUB;                      // query rows per step
+    static constexpr int QT_BYTES = QM * DP * 2;              // one of Q / dO slice
+    static constexpr int QBUF_BYTES = 2 * QT_BYTES + 8 * QM;  // Q, dO, lse[QM], delta[QM]
     // LDS map: [K tile | V tile] while loading; then V_IN_LDS: [Q bufs (over K) ... | V tile],
     // else: [unused K | Q bufs (over V)]
     static constexpr int OFF_K = 0;
@@ -103,7 +108,7 @@ struct BwdCfg {
     static constexpr int OUT_LDS = NW * 32 * OUT_ROWB;
     static constexpr int LDS_BYTES = MAIN_LDS > OUT_LDS ? MAIN_LDS : OUT_LDS;
     static constexpr int KV_CH = KB * CPR / NT;               // chunks per thread per K (or V) tile
-    static constexpr int QCH = (BW_QM * CPR + NT - 1) / NT;   // chunks per thread per Q (or dO) slice
+    static constexpr int QCH = (QM * CPR + NT - 1) / NT;      // chunks per thread per Q (or dO) slice
 };
 
 template <int DP, bool BF16, int NW, bool FAST>
@@ -112,7 +117,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
     constexpr int CPR = Cfg::CPR, NT = Cfg::NT, KB = Cfg::KB;
     constexpr int KS = DP / 16, NDB = DP / 32;
-    constexpr int QCH = Cfg::QCH;
+    constexpr int QCH = Cfg::QCH, BW_QM = Cfg::QM, QSUB = Cfg::QSUB;
     constexpr bool V_IN_LDS = Cfg::V_IN_LDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -197,7 +202,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
 
     // ---- Q / dO slice staging (register prefetch, two LDS buffers) ----
     i32x4 qreg[QCH], doreg[QCH];
-    float rowc = 0.f;  // lse (tid < 32) or delta (32 <= tid < 64) of the slice
+    float rowc = 0.f;  // lse (tid < QM) or delta (QM <= tid < 2 QM) of the slice
     // Step -> (query head of the GQA group, 32-row slice).  Slices are swept from the last one
     // down: under a causal mask every key block sees the last rows, so the co-resident blocks of
     // a pair read the same slice at about the same time.  Kept as counters (an integer division
@@ -245,26 +250,32 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             doreg[i] = ok ? *(const i32x4 *)(dog + (int64_t)(q0 + row) * p.do_rs + ch * 8) : i32x4{0, 0, 0, 0};
         }
         }
-        if (tid < 64) {
-            const int row = q0 + (tid & 31);
+        if (tid < 2 * BW_QM) {
+            const int row = q0 + (tid & (BW_QM - 1));
             const bool ok = row < sq;
-            if (tid < 32) rowc = ok ? p.lse[((int64_t)bidb * p.h + bidh) * p.seqlen_q + row] : INFINITY;
+            if (tid < BW_QM) rowc = ok ? p.lse[((int64_t)bidb * p.h + bidh) * p.seqlen_q + row] : INFINITY;
             else rowc = ok ? p.dsoftmax_sum[((int64_t)bidb * p.h + bidh) * p.seqlen_q_rounded + row] : 0.f;
         }
     };
-    int st_off[QCH];
+    // LDS store offsets are loop invariant; at d = 256 the registers to keep them are not there
+    constexpr bool HOIST_ST = DP <= 128;
+    int st_off[HOIST_ST ? QCH : 1];
+    if constexpr (HOIST_ST) {
 #pragma unroll
-    for (int i = 0; i < QCH; i++) st_off[i] = lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
+        for (int i = 0; i < QCH; i++) st_off[i] = lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
+    }
     auto store_slice = [&](int buf) {
         char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
 #pragma unroll
         for (int i = 0; i < QCH; i++) {
             if (tid + i * NT < BW_QM * CPR) {
-                *(i32x4 *)(qb + st_off[i]) = qreg[i];
-                *(i32x4 *)(qb + Cfg::QT_BYTES + st_off[i]) = doreg[i];
+                const int off = HOIST_ST ? st_off[HOIST_ST ? i : 0]
+                                         : lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
+                *(i32x4 *)(qb + off) = qreg[i];
+                *(i32x4 *)(qb + Cfg::QT_BYTES + off) = doreg[i];
             }
         }
-        if (tid < 64) ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = rowc;
+        if (tid < 2 * BW_QM) ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = rowc;
     };
 
     int cur_h = 0, cur_m = m_max - 1, nxt_h = 0, nxt_m = m_max - 1;
@@ -280,18 +291,26 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
 #endif
     int buf = 0;
     for (int step = 0; step < total_steps; step++) {
-        const int bidh = hk * p.h_ratio + cur_h, q0 = cur_m * BW_QM;
+        const int bidh = hk * p.h_ratio + cur_h, q0s = cur_m * BW_QM;
         const bool has_next = step + 1 < total_steps;
         STAMP(7);
         if (has_next) load_slice(nxt_h, nxt_m);
         STAMP(0);
 
-        const char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
-        const char *dob = qb + Cfg::QT_BYTES;
-        const float *lse_s = (const float *)(qb + 2 * Cfg::QT_BYTES);
-        const float *dl_s = lse_s + 32;
+        const char *qb0 = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
+        const float *lse_s0 = (const float *)(qb0 + 2 * Cfg::QT_BYTES);
+        float alibi = 0.f;
+        if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
 
-        // a wave whose 32 keys are invisible to all 32 rows of this slice only helps with staging
+#pragma unroll
+        for (int sub = QSUB - 1; sub >= 0; sub--) {  // 32-row sub-blocks, last rows first
+        const int q0 = q0s + 32 * sub;
+        const char *qb = qb0 + 32 * sub * (DP * 2);
+        const char *dob = qb + Cfg::QT_BYTES;
+        const float *lse_s = lse_s0 + 32 * sub;
+        const float *dl_s = lse_s0 + BW_QM + 32 * sub;
+
+        // a wave whose 32 keys are invisible to all 32 rows of this sub-block only helps with staging
         bool skip = false;
         if (p.is_causal || p.is_local) skip = kw0 >= q0 + 32 + sk - sq + p.wr;
         if (p.is_local) skip = skip || (kw0 + 32 <= q0 + sk - sq - p.wl);
@@ -309,8 +328,6 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         // ---- P = exp2(S*c - LSE*log2e) under the forward's mask and bias ----
         {
             const int col = kw0 + r;
-            float alibi = 0.f;
-            if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
             const bool masked_tile = has_alibi || (kw0 + 32 > sk) || (q0 + 32 > sq) ||
                                      ((p.is_causal || p.is_local) && (kw0 + 32 > q0 + 1 + sk - sq + p.wr)) ||
                                      (p.is_local && (kw0 < q0 + 31 + sk - sq - p.wl));
@@ -385,6 +402,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }
         STAMP(4);
         }  // !skip
+        }  // sub
 
         if (has_next) store_slice(buf ^ 1);
         STAMP(5);
@@ -463,8 +481,12 @@ static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
 
 template <int DP, bool BF16, int NW>
 static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
-    return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
-                              : launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
+    if constexpr (DP == 256) {  // no registers to spare for the buffer-load offsets
+        return launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
+    } else {
+        return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
+                                  : launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
