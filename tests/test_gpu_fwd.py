@@ -437,3 +437,23 @@ def test_kvcache_without_seqlens_and_seqlen_k_zero():
     k0 = torch.empty(2, 0, 4, 64, device="cuda", dtype=torch.float16)
     o0, l0, _ = fa.flash_attn_func(q, k0, k0, return_attn_probs=True)
     assert torch.equal(o0, torch.zeros_like(o0)) and torch.isposinf(l0).all()
+
+
+def test_kvcache_gqa_decode_writes_caller_shaped_out():
+    """seqlen_q = 1 with grouped heads takes the (b, ngroups, h_k, d) fold; an `out` of the caller's
+    own shape (b, 1, h, d) is filled in place.  (The reference checks `out` against the folded shape
+    there, flash_api.cpp:787, and raises; both shapes are accepted here.)"""
+    import vllm_flash_attn as fa
+    torch.manual_seed(11)
+    b, kv, h, hk, d = 3, 300, 8, 2, 64
+    q = torch.randn(b, 1, h, d, device="cuda", dtype=torch.float16)
+    kc = torch.randn(b, kv, hk, d, device="cuda", dtype=torch.float16)
+    vc = torch.randn_like(kc)
+    lens = torch.tensor([300, 17, 129], dtype=torch.int32, device="cuda")
+    ref = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True)
+    out = torch.full_like(q, float("nan"))
+    got = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, out=out)
+    assert got.shape == q.shape and torch.equal(out, ref) and torch.equal(got, ref)
+    folded = torch.full((b, h // hk, hk, d), float("nan"), device="cuda", dtype=torch.float16)
+    fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, out=folded)
+    assert torch.equal(folded.transpose(1, 2).reshape(b, 1, h, d), ref)

@@ -100,6 +100,11 @@ static void fill_common(const vfa_params *p, KParams &k, int seqlen_q_for_fold, 
     k.k_cumulative = p->cu_seqlens_k ? p->is_seqlens_k_cumulative : 1;
     k.block_table = p->block_table; k.bt_bs = p->block_table_batch_stride;
     k.page_size = p->block_table ? p->page_block_size : 1;
+    k.page_shift = -1;
+    if (k.page_size > 0 && (k.page_size & (k.page_size - 1)) == 0) {
+        k.page_shift = 0;
+        while ((1 << k.page_shift) < k.page_size) k.page_shift++;
+    }
     k.cache_batch_idx = p->cache_batch_idx;
     k.alibi_slopes = p->alibi_slopes; k.alibi_bs = (int)p->alibi_slopes_batch_stride;
     k.scale = p->softmax_scale;

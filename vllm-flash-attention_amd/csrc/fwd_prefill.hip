@@ -150,6 +150,20 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     const unsigned k_voff = colok0 ? (unsigned)(((tid / CPR) * (int)p.k_rs + (tid % CPR) * 8) * 2) : 0x80000000u;
     const unsigned v_voff = colok0 ? (unsigned)(((tid / CPR) * (int)p.v_rs + (tid % CPR) * 8) * 2) : 0x80000000u;
     const unsigned k_rs2 = (unsigned)p.k_rs * 2, v_rs2 = (unsigned)p.v_rs * 2;
+    // Paged KV: the page ids of a tile are fetched one tile ahead of its rows, so that the
+    // block-table lookup is not a second memory latency in front of the K/V loads.
+    int pg[FAST ? 1 : CH];
+    auto load_pages = [&](int n) {
+        if constexpr (!FAST) {
+            if (!bt || n < 0) return;
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int grow = n * BN + (tid + i * NT) / CPR;
+                const int safe = grow < sk ? grow : 0;
+                pg[i] = bt[p.page_shift >= 0 ? safe >> p.page_shift : safe / p.page_size];
+            }
+        }
+    };
     auto load_tile = [&](int n) {
         if constexpr (FAST) {
             constexpr int RSTEP = NT / CPR;  // rows between a lane's chunks
@@ -169,12 +183,11 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             const int grow = n * BN + row;
             const bool ok = grow < sk && ch * 8 < p.d;
             int64_t ko, vo;
-            if (bt) {  // paged: csrc/flash_attn/src/utils.h:297-315
+            if (bt) {  // paged: csrc/flash_attn/src/utils.h:297-315; page ids fetched a tile ahead
                 const int safe = ok ? grow : 0;
-                const int page = bt[safe / p.page_size];
-                const int inpage = safe % p.page_size;
-                ko = (int64_t)page * p.k_bs + (int64_t)inpage * p.k_rs;
-                vo = (int64_t)page * p.v_bs + (int64_t)inpage * p.v_rs;
+                const int inpage = p.page_shift >= 0 ? safe & (p.page_size - 1) : safe % p.page_size;
+                ko = (int64_t)pg[i] * p.k_bs + (int64_t)inpage * p.k_rs;
+                vo = (int64_t)pg[i] * p.v_bs + (int64_t)inpage * p.v_rs;
             } else {
                 ko = (int64_t)grow * p.k_rs;
                 vo = (int64_t)grow * p.v_rs;
@@ -242,7 +255,9 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             v_rd[db][e] = lds_off<DP>(4 * hh + tr_q + 8 * e, 4 * db + 2 * tr_g + (tr_p >> 1)) + 8 * (tr_p & 1);
     constexpr int ROWB = DP * 2;
 
+    load_pages(n_max - 1);
     load_tile(n_max - 1);
+    if (n_max - 2 >= n_min) load_pages(n_max - 2);
     store_tile(std::integral_constant<int, 0>{});
     __syncthreads();
 
@@ -256,7 +271,10 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         constexpr int BUF = decltype(BUFC)::value;
         const bool has_next = n > n_min;
         STAMP(7);
-        if (has_next) load_tile(n - 1);
+        if (has_next) {
+            load_tile(n - 1);
+            if (n - 2 >= n_min) load_pages(n - 2);
+        }
         STAMP(0);
 
         const char *kb = smem + BUF * Cfg::TILE_BYTES;

@@ -150,6 +150,19 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     }
 
     i32x4 kreg[CH], vreg[CH];
+    // Paged KV: the page ids of a tile are fetched one tile ahead of its rows, so that the
+    // block-table lookup is not a second memory latency in front of every K/V load (decode is
+    // HBM-bound and prefetches only one tile deep).
+    int pg[CH];
+    auto load_pages = [&](int n) {
+        if (!bt) return;
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int grow = n * DEC_BN + (tid + i * DEC_NT) / CPR;
+            const int safe = grow < sk ? grow : 0;
+            pg[i] = bt[p.page_shift >= 0 ? safe >> p.page_shift : safe / p.page_size];
+        }
+    };
     auto load_tile = [&](int n) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
@@ -160,10 +173,9 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             int64_t ko, vo;
             if (bt) {  // csrc/flash_attn/src/utils.h:297-315
                 const int safe = ok ? grow : 0;
-                const int page = bt[safe / p.page_size];
-                const int inpage = safe % p.page_size;
-                ko = (int64_t)page * p.k_bs + (int64_t)inpage * p.k_rs;
-                vo = (int64_t)page * p.v_bs + (int64_t)inpage * p.v_rs;
+                const int inpage = p.page_shift >= 0 ? safe & (p.page_size - 1) : safe % p.page_size;
+                ko = (int64_t)pg[i] * p.k_bs + (int64_t)inpage * p.k_rs;
+                vo = (int64_t)pg[i] * p.v_bs + (int64_t)inpage * p.v_rs;
             } else {
                 ko = (int64_t)grow * p.k_rs;
                 vo = (int64_t)grow * p.v_rs;
@@ -227,11 +239,16 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     const char *vb = smem + Cfg::TILE_BYTES;
     const int wrow = 32 * wave;  // this wave's rows of the staged tile
 
+    load_pages(n_max - 1);
     load_tile(n_max - 1);
+    if (n_max - 1 > n_min) load_pages(n_max - 2);
     for (int n = n_max - 1; n >= n_min; n--) {
         store_tile();
         __syncthreads();
-        if (n > n_min) load_tile(n - 1);
+        if (n > n_min) {
+            load_tile(n - 1);
+            if (n - 1 > n_min) load_pages(n - 2);
+        }
 
         f32x16 s;
 #pragma unroll

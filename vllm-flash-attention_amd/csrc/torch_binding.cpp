@@ -408,7 +408,16 @@ std::vector<Tensor> fwd_kvcache(Tensor &q, const Tensor &kcache, const Tensor &v
         TORCH_CHECK(out.scalar_type() == q.scalar_type(), "Output must have the same dtype as inputs");
         expect_gpu(out, "out");
         TORCH_CHECK(out.stride(-1) == 1, "Output tensor must have contiguous last dimension");
-        expect_shape(out, "out", {b, sq, h, d_og});
+        // The reference checks `out` against the FOLDED query shape here (flash_api.cpp:787), so a
+        // caller-shaped (b, 1, h, d) output is rejected whenever the GQA decode fold applies, while
+        // mha_fwd re-views it (flash_api.cpp:327-330).  Accept both: the caller's shape is viewed
+        // like the query, the folded shape is taken as is.
+        if (fold && out.dim() == 4 && out.size(1) == 1 && out.size(2) == hk * g) {
+            expect_shape(out, "out", {b, 1, hk * g, d_og});
+            out = out.reshape({b, hk, g, d_og}).transpose(1, 2);
+        } else {
+            expect_shape(out, "out", {b, sq, h, d_og});
+        }
         if (d_og % 8 != 0) out = torch::empty_like(qp);
     } else {
         out = torch::empty_like(qp);

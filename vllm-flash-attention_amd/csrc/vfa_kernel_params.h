@@ -24,6 +24,7 @@ struct KParams {
     const int *block_table;     // paged KV: (b, bt_bs) page ids, or null
     int64_t bt_bs;
     int page_size;
+    int page_shift;             // log2(page_size) when it is a power of two, else -1
     const int *cache_batch_idx; // b or null
     const float *alibi_slopes;  // (h) or (b,h) or null
     int alibi_bs;               // 0 for (h)
