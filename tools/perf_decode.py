@@ -75,8 +75,26 @@ def prefill_paged():
         print(f"prefill paged, page {page}: {t:.3f} ms  {flops / t / 1e9:.0f} TF  (max diff {err:.1e})", flush=True)
 
 
+def small_batch():
+    """Decode at small batch / long context: the split-KV path and its combine kernel."""
+    torch.manual_seed(0)
+    h, hk, d, dt = 32, 8, 128, torch.float16
+    for b, kv in ((1, 8192), (1, 32768), (1, 131072), (4, 32768), (16, 8192), (32, 4096), (64, 2048)):
+        q = torch.randn(b, 1, h, d, device="cuda", dtype=dt)
+        kc = torch.randn(b, kv, hk, d, device="cuda", dtype=dt)
+        vc = torch.randn_like(kc)
+        lens = torch.full((b,), kv, dtype=torch.int32, device="cuda")
+        gb = 2.0 * b * kv * hk * d * 2 / 1e9
+        t = med_ms(lambda: fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True))
+        t1 = med_ms(lambda: fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, num_splits=1))
+        print(f"b{b} kv{kv}: heuristic splits {t * 1000:.1f} us ({gb / t * 1000:.0f} GB/s)   num_splits=1 {t1 * 1000:.1f} us "
+              f"({gb / t1 * 1000:.0f} GB/s)", flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "prefill":
         prefill_paged()
+    elif len(sys.argv) > 1 and sys.argv[1] == "small":
+        small_batch()
     else:
         main()

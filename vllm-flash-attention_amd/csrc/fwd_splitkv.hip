@@ -388,42 +388,64 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 }
 
 // LSE-weighted merge of the splits: combine_attn_seqk_parallel, flash_fwd_kernel.h:1092-1250.
-// One thread per (row, 8-wide d chunk); rows = b*h*seqlen_q laid out like oaccum.
+// Rows = b*h*seqlen_q laid out like oaccum.
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 fwd_combine_kernel(const KParams p) {
+    // One workgroup per output row (batch, head, query).  The splits' LSEs go through LDS once;
+    // the 256 threads then cover (16-byte output chunk) x (split lane): every thread sums the
+    // partial outputs of the splits congruent to its lane, with its loads independent of each
+    // other, and the lanes are added through LDS.  (A thread per chunk looping over up to 128
+    // splits three times is latency-bound: 40 us for one sequence.)
+    __shared__ float s_lse[128];
+    __shared__ float s_part[256 * 8];
+    const int tid = threadIdx.x;
     const int cpr = p.d / 8;
+    const int nlane = 256 / cpr;                 // split lanes
     const int64_t total_rows = (int64_t)p.b * p.h * p.seqlen_q;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total_rows * cpr) return;
-    const int64_t row = idx / cpr;
-    const int ch = (int)(idx % cpr);
+    const int64_t row = blockIdx.x;
     const int sqi = (int)(row % p.seqlen_q);
     const int bh = (int)(row / p.seqlen_q);
     const int bidb = bh / p.h, bidh = bh % p.h;
     const BlockInfo bi(p, bidb);
     if (sqi >= bi.sq) return;
 
+    if (tid < p.num_splits) s_lse[tid] = p.lseaccum[tid * total_rows + row];
+    __syncthreads();
     float lmax = -INFINITY;
-    for (int s = 0; s < p.num_splits; s++) lmax = fmaxf(lmax, p.lseaccum[s * total_rows + row]);
-    if (lmax == -INFINITY) lmax = 0.f;                       // :1156
+    for (int s = 0; s < p.num_splits; s++) lmax = fmaxf(lmax, s_lse[s]);
+    if (lmax == -INFINITY) lmax = 0.f;                       // flash_fwd_kernel.h:1156
     float lsum = 0.f;
-    for (int s = 0; s < p.num_splits; s++) lsum += expf(p.lseaccum[s * total_rows + row] - lmax);
+    for (int s = 0; s < p.num_splits; s++) lsum += expf(s_lse[s] - lmax);
     const float lse = (lsum == 0.f || lsum != lsum) ? INFINITY : logf(lsum) + lmax;  // :1164
-    if (ch == 0) p.lse[row] = lse;
+    if (tid == 0) p.lse[row] = lse;
+
+    const int ch = tid % cpr, sl = tid / cpr;
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-    for (int s = 0; s < p.num_splits; s++) {
-        const float w = expf(p.lseaccum[s * total_rows + row] - lse);   // :1172
-        const float *src = p.oaccum + (s * total_rows + row) * p.d + ch * 8;
-        a0 += *(const f32x4 *)src * w;
-        a1 += *(const f32x4 *)(src + 4) * w;
+    if (sl < nlane) {
+        for (int s = sl; s < p.num_splits; s += nlane) {
+            const float w = expf(s_lse[s] - lse);            // :1172
+            const float *src = p.oaccum + (s * total_rows + row) * p.d + ch * 8;
+            a0 += *(const f32x4 *)src * w;
+            a1 += *(const f32x4 *)(src + 4) * w;
+        }
     }
-    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
-                         (int64_t)bidh * p.o_hs + (int64_t)sqi * p.o_rs + ch * 8;
-    i32x4 w;
-    w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
-    w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
-    *(i32x4 *)og = w;
+    *(f32x4 *)(s_part + tid * 8) = a0;
+    *(f32x4 *)(s_part + tid * 8 + 4) = a1;
+    __syncthreads();
+    if (tid < cpr) {
+        // lanes are added in index order: the result does not depend on timing
+        for (int l = 1; l < nlane; l++) {
+            a0 += *(const f32x4 *)(s_part + (l * cpr + tid) * 8);
+            a1 += *(const f32x4 *)(s_part + (l * cpr + tid) * 8 + 4);
+        }
+        unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
+                             (int64_t)bidh * p.o_hs + (int64_t)sqi * p.o_rs + tid * 8;
+        i32x4 w;
+        w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
+        w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
+        *(i32x4 *)og = w;
+    }
 }
 
 // Append knew/vnew to the cache at [seqlen_k_cache, seqlen_k_cache + seqlen_knew), K rotated with
@@ -483,8 +505,7 @@ static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.num_splits > 1) {
-        const long long items = (long long)p.b * p.h * p.seqlen_q * (p.d / 8);
-        const unsigned cblocks = (unsigned)((items + 255) / 256);
+        const unsigned cblocks = (unsigned)((long long)p.b * p.h * p.seqlen_q);
         if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_kernel<true>, dim3(cblocks), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL(fwd_combine_kernel<false>, dim3(cblocks), dim3(256), 0, stream, p);
         e = hipGetLastError();
