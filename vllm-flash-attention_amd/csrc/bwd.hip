@@ -9,11 +9,11 @@
 //
 // Three kernels, no atomics (dq, dk, dv are bitwise reproducible):
 //   bwd_preprocess : delta (the softmax_d output), one 16-lane group per query row
-//   bwd_dkdv       : KEY-stationary.  One workgroup (4 waves) per 128-key block of one (batch, KV
-//                    head); each wave owns 32 keys, holds their K / V MFMA fragments and the
-//                    dK^T / dV^T accumulators in registers, and the workgroup sweeps the query heads
-//                    of the GQA group x 32-row query slices (staged through LDS), so dK / dV need no
-//                    reduction across workgroups.  S and dP are computed with the key on the MFMA
+//   bwd_dkdv       : KEY-stationary.  One workgroup (8 waves, or 4 for short key sequences) per
+//                    256- (128-) key block of one (batch, KV head); each wave owns 32 keys, holds
+//                    their K MFMA fragments and the dK^T / dV^T accumulators in registers, and the
+//                    workgroup sweeps the query heads of the GQA group x 32- or 64-row query slices
+//                    (staged through LDS), so dK / dV need no reduction across workgroups.  S and dP are computed with the key on the MFMA
 //                    lane, so P and dS are directly the B operands of dV^T += dO^T P and
 //                    dK^T += Q^T dS (A operands by transposed LDS reads of the slice).
 //   bwd_dq         : QUERY-stationary, the forward kernel's structure: a wave owns 32 query rows
