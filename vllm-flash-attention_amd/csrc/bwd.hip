@@ -91,7 +91,7 @@ struct BwdCfg {
     static constexpr int KV_BYTES = KB * DP * 2;              // one of K / V
     // Two sub-blocks at d = 64 (measured +29 % on MI355X); at d = 128 the taller slice costs the
     // registers the 8-wave kernel does not have (spills, -14 %).
-    static constexpr int QSUB = (NW == 8 && DP == 64) ? 2 : 1;
+    static constexpr int QSUB = (NW == 8 && DP <= 128) ? 2 : 1;
     static constexpr int QM = 32 * QSUB;                      // query rows per step
     static constexpr int QT_BYTES = QM * DP * 2;              // one of Q / dO slice
     static constexpr int QBUF_BYTES = 2 * QT_BYTES + 8 * QM;  // Q, dO, lse[QM], delta[QM]
@@ -201,7 +201,6 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const int total_steps = n_steps_per_head * p.h_ratio;
 
     // ---- Q / dO slice staging (register prefetch, two LDS buffers) ----
-    i32x4 qreg[QCH], doreg[QCH];
     float rowc = 0.f;  // lse (tid < QM) or delta (QM <= tid < 2 QM) of the slice
     // Step -> (query head of the GQA group, 32-row slice).  Slices are swept from the last one
     // down: under a causal mask every key block sees the last rows, so the co-resident blocks of
@@ -216,16 +215,29 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // FAST: Q / dO rows come through buffer loads whose descriptor (rebuilt per head, it is four
     // scalar words) ends at the last valid query row, so the row tail and the head-dim padding
     // read as zeros with no predication and no 64-bit address arithmetic per chunk.
-    unsigned q_voff[QCH], do_voff[QCH];
-#pragma unroll
-    for (int i = 0; i < QCH; i++) {
+    constexpr bool HOIST_VOFF = DP <= 64;
+    auto voff_of = [&](int i, int64_t rs) -> unsigned {
         const int c = tid + i * NT;
         const int row = c / CPR, ch = c % CPR;
         const bool ok = c < BW_QM * CPR && ch * 8 < p.d;
-        q_voff[i] = ok ? (unsigned)((row * (int)p.q_rs + ch * 8) * 2) : 0x80000000u;
-        do_voff[i] = ok ? (unsigned)((row * (int)p.do_rs + ch * 8) * 2) : 0x80000000u;
+        return ok ? (unsigned)((row * (int)rs + ch * 8) * 2) : 0x80000000u;
+    };
+    unsigned q_voff[HOIST_VOFF ? QCH : 1], do_voff[HOIST_VOFF ? QCH : 1];
+    if constexpr (HOIST_VOFF) {
+#pragma unroll
+        for (int i = 0; i < QCH; i++) {
+            q_voff[i] = voff_of(i, p.q_rs);
+            do_voff[i] = voff_of(i, p.do_rs);
+        }
     }
-    auto load_slice = [&](const int gh, const int m) {
+    // SPLIT (two chunks of 32 rows, two sub-blocks): chunk 0 of the next slice is loaded at the top
+    // of a step and written to LDS after the first sub-block, chunk 1 is loaded then and written
+    // at the end, so one set of staging registers serves both (the registers are what limits the
+    // slice height at d = 128).
+    constexpr bool SPLIT = QCH == 2 && QSUB == 2;
+    constexpr int NSTG = SPLIT ? 1 : QCH;  // staging register sets
+    i32x4 qreg[NSTG], doreg[NSTG];
+    auto load_chunk = [&](const int gh, const int m, const int i, const int slot) {
         const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
         const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
         const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
@@ -235,21 +247,20 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const auto do_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)dog, 0, (unsigned)(((int64_t)(sq - 1) * p.do_rs + p.d) * 2), 0x00020000);
             const unsigned q_t = (unsigned)q0 * (unsigned)p.q_rs * 2, do_t = (unsigned)q0 * (unsigned)p.do_rs * 2;
-#pragma unroll
-            for (int i = 0; i < QCH; i++) {
-                qreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, q_voff[i] + q_t, 0, 0));
-                doreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(do_rsrc, do_voff[i] + do_t, 0, 0));
-            }
+            const unsigned qv = HOIST_VOFF ? q_voff[HOIST_VOFF ? i : 0] : voff_of(i, p.q_rs);
+            const unsigned dv_ = HOIST_VOFF ? do_voff[HOIST_VOFF ? i : 0] : voff_of(i, p.do_rs);
+            qreg[slot] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, qv + q_t, 0, 0));
+            doreg[slot] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(do_rsrc, dv_ + do_t, 0, 0));
         } else {
-#pragma unroll
-        for (int i = 0; i < QCH; i++) {
             const int c = tid + i * NT;
             const int row = c / CPR, ch = c % CPR;
             const bool ok = c < BW_QM * CPR && (q0 + row) < sq && ch * 8 < p.d;
-            qreg[i] = ok ? *(const i32x4 *)(qg + (int64_t)(q0 + row) * p.q_rs + ch * 8) : i32x4{0, 0, 0, 0};
-            doreg[i] = ok ? *(const i32x4 *)(dog + (int64_t)(q0 + row) * p.do_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            qreg[slot] = ok ? *(const i32x4 *)(qg + (int64_t)(q0 + row) * p.q_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            doreg[slot] = ok ? *(const i32x4 *)(dog + (int64_t)(q0 + row) * p.do_rs + ch * 8) : i32x4{0, 0, 0, 0};
         }
-        }
+    };
+    auto load_rowc = [&](const int gh, const int m) {
+        const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
         if (tid < 2 * BW_QM) {
             const int row = q0 + (tid & (BW_QM - 1));
             const bool ok = row < sq;
@@ -257,32 +268,54 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             else rowc = ok ? p.dsoftmax_sum[((int64_t)bidb * p.h + bidh) * p.seqlen_q_rounded + row] : 0.f;
         }
     };
+    // whole slice at once (prologue, and every step when !SPLIT)
+    auto load_slice = [&](const int gh, const int m) {
+        static_assert(!SPLIT || QCH == 2, "split staging is written for two chunks");
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int i = 0; i < QCH; i++) load_chunk(gh, m, i, i);
+        }
+        load_rowc(gh, m);
+    };
     // LDS store offsets are loop invariant; at d = 256 the registers to keep them are not there
-    constexpr bool HOIST_ST = DP <= 128;
+    constexpr bool HOIST_ST = DP <= 64;
     int st_off[HOIST_ST ? QCH : 1];
     if constexpr (HOIST_ST) {
 #pragma unroll
         for (int i = 0; i < QCH; i++) st_off[i] = lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
     }
-    auto store_slice = [&](int buf) {
+    auto store_chunk = [&](int buf, const int i, const int slot) {
         char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
-#pragma unroll
-        for (int i = 0; i < QCH; i++) {
-            if (tid + i * NT < BW_QM * CPR) {
-                const int off = HOIST_ST ? st_off[HOIST_ST ? i : 0]
-                                         : lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
-                *(i32x4 *)(qb + off) = qreg[i];
-                *(i32x4 *)(qb + Cfg::QT_BYTES + off) = doreg[i];
-            }
+        if (tid + i * NT < BW_QM * CPR) {
+            const int off = HOIST_ST ? st_off[HOIST_ST ? i : 0]
+                                     : lds_off<DP>((tid + i * NT) / CPR, (tid + i * NT) % CPR);
+            *(i32x4 *)(qb + off) = qreg[slot];
+            *(i32x4 *)(qb + Cfg::QT_BYTES + off) = doreg[slot];
         }
+    };
+    auto store_rowc = [&](int buf) {
+        char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
         if (tid < 2 * BW_QM) ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = rowc;
+    };
+    auto store_slice = [&](int buf) {
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int i = 0; i < QCH; i++) store_chunk(buf, i, i);
+        }
+        store_rowc(buf);
     };
 
     int cur_h = 0, cur_m = m_max - 1, nxt_h = 0, nxt_m = m_max - 1;
     advance(nxt_h, nxt_m);
     if (total_steps > 0) load_slice(cur_h, cur_m);
+    if (SPLIT && total_steps > 0) load_chunk(cur_h, cur_m, 0, 0);
     __syncthreads();  // every wave has its fragments: the freed tile space becomes the Q buffers
     if (total_steps > 0) store_slice(0);
+    if (SPLIT && total_steps > 0) {
+        store_chunk(0, 0, 0);
+        load_chunk(cur_h, cur_m, 1, 0);
+        store_chunk(0, 1, 0);
+    }
     __syncthreads();
 
 #ifdef VFA_STAMP
@@ -294,7 +327,10 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         const int bidh = hk * p.h_ratio + cur_h, q0s = cur_m * BW_QM;
         const bool has_next = step + 1 < total_steps;
         STAMP(7);
-        if (has_next) load_slice(nxt_h, nxt_m);
+        if (has_next) {
+            load_slice(nxt_h, nxt_m);
+            if constexpr (SPLIT) load_chunk(nxt_h, nxt_m, 0, 0);
+        }
         STAMP(0);
 
         const char *qb0 = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
@@ -402,9 +438,19 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }
         STAMP(4);
         }  // !skip
+        __builtin_amdgcn_sched_barrier(0);  // keep the sub-blocks apart: interleaving them only adds live registers
+        if constexpr (SPLIT) {
+            if (sub == QSUB - 1 && has_next) {  // between the two sub-blocks
+                store_chunk(buf ^ 1, 0, 0);
+                load_chunk(nxt_h, nxt_m, 1, 0);
+            }
+        }
         }  // sub
 
-        if (has_next) store_slice(buf ^ 1);
+        if (has_next) {
+            store_slice(buf ^ 1);
+            if constexpr (SPLIT) store_chunk(buf ^ 1, 1, 0);
+        }
         STAMP(5);
         __syncthreads();
         STAMP(6);
