@@ -89,8 +89,8 @@ struct BwdCfg {
     static constexpr bool V_IN_LDS = NW == 8;
     static constexpr int CPR = DP / 8;
     static constexpr int KV_BYTES = KB * DP * 2;              // one of K / V
-    // Two sub-blocks at d = 64 (measured +29 % on MI355X); at d = 128 the taller slice costs the
-    // registers the 8-wave kernel does not have (spills, -14 %).
+    // Sub-blocks per slice, 8-wave kernel: 2 (measured on MI355X: +29 % at d = 64, +4 % at d = 128,
+    // where the staging registers had to be shared between the chunks to make room).
     static constexpr int QSUB = (NW == 8 && DP <= 128) ? 2 : 1;
     static constexpr int QM = 32 * QSUB;                      // query rows per step
     static constexpr int QT_BYTES = QM * DP * 2;              // one of Q / dO slice
