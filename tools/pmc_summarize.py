@@ -27,8 +27,11 @@ def collect(d):
             out.setdefault(k, {})["mfma"] = {
                 "sq_valu_mfma_busy_cycles": mf, "grbm_gui_active": gui,
                 "sq_busy_cycles": cs.get("SQ_BUSY_CYCLES", [0.0])[0] / n,
-                # busy cycles are summed over the chip's 1024 SIMDs (256 CUs x 4)
-                "mfma_busy_frac": mf / (gui * 1024.0) if gui else None}
+                # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (it equals 32 cycles x
+                # the number of 32x32x16 MFMAs issued); GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+                # so one XCD's wall-clock cycles are gui / 8 and the busy share is
+                # mfma / (gui / 8 * 1024).
+                "mfma_busy_frac": mf / (gui * 128.0) if gui else None}
         if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
             continue
         f = cs["FETCH_SIZE"][0] / max(1, len(cs["FETCH_SIZE"][1]))
