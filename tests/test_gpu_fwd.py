@@ -457,3 +457,48 @@ def test_kvcache_gqa_decode_writes_caller_shaped_out():
     folded = torch.full((b, h // hk, hk, d), float("nan"), device="cuda", dtype=torch.float16)
     fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, out=folded)
     assert torch.equal(folded.transpose(1, 2).reshape(b, 1, h, d), ref)
+
+
+def test_decode_is_graph_capturable():
+    """vLLM replays its decode step from a captured graph: the whole call (wrapper, extension,
+    C ABI) must only enqueue work on the capturing stream.  Capture the paged split-KV decode and
+    the contiguous single-pass decode, change the inputs in place, replay, compare with eager."""
+    import vllm_flash_attn as fa
+    torch.manual_seed(12)
+    b, kv, h, hk, d, page = 4, 1024, 8, 2, 128, 16
+    dt = torch.float16
+    q = torch.randn(b, 1, h, d, device="cuda", dtype=dt)
+    kc = torch.randn(b, kv, hk, d, device="cuda", dtype=dt)
+    vc = torch.randn_like(kc)
+    lens = torch.tensor([1024, 700, 33, 512], dtype=torch.int32, device="cuda")
+    nb = b * kv // page
+    perm = torch.randperm(nb, device="cuda")
+    bt = perm.view(b, kv // page).to(torch.int32)
+    kp = torch.empty(nb, page, hk, d, device="cuda", dtype=dt)
+    vp = torch.empty_like(kp)
+    kp[perm] = kc.view(nb, page, hk, d)
+    vp[perm] = vc.view(nb, page, hk, d)
+    out_p = torch.empty_like(q)
+    out_c = torch.empty_like(q)
+
+    def step():
+        fa.flash_attn_with_kvcache(q, kp, vp, cache_seqlens=lens, block_table=bt, causal=True, out=out_p)
+        fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, num_splits=1, out=out_c)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()  # warm-up outside capture (lazy module / attribute set-up)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    q.copy_(torch.randn_like(q))          # new query, same buffers
+    lens.copy_(torch.tensor([5, 1024, 900, 64], dtype=torch.int32, device="cuda"))
+    g.replay()
+    torch.cuda.synchronize()
+    got_p, got_c = out_p.clone(), out_c.clone()
+    ref = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, num_splits=1)
+    assert torch.equal(got_c, ref)
+    assert (got_p.float() - ref.float()).abs().max().item() <= 2e-3

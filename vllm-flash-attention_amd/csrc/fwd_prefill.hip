@@ -442,12 +442,10 @@ static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
     auto kern = fwd_prefill_kernel<DP, BF16, NW, FAST>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
+    if (Cfg::LDS_BYTES > 64 * 1024) {  // per device and cheap: set on every launch
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p,
                        n_mblocks);
