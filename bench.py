@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: attention forward+backward TFLOPS at BASELINE.json's headline config
+"""Headline benchmark: attention forward+backward TFLOPS at the headline configuration
 (batch 8, seqlen 4096, 32 heads, headdim 128, bf16, causal) on N MI355X GPUs.
 
   python bench.py --gpus N --steps K --warmup W
@@ -44,7 +44,7 @@ C4_WINDOW = (1024, 0)
 
 
 def visible_pairs(seqlens_q, seqlens_k, causal, window):
-    """Sum over rows of the number of visible keys (the masked FLOP count of SURVEY 8d)."""
+    """Sum over rows of the number of visible keys (the masked FLOP count: 4 h d times this sum)."""
     wl, wr = window
     if causal:
         wr = 0

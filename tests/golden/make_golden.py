@@ -173,7 +173,7 @@ def kvcache_case(ref, name, dtype, b, sq, sk, h, hk, d, causal, page, seed=0, al
 
 def main():
     ref = load_reference_oracle()
-    # (1) BASELINE config 1: fp32, also checked against torch SDPA in the test
+    # (1) plumbing configuration: fp32, also checked against torch SDPA in the test
     dense_case(ref, "c1_fp32_b2_s128_h4_d64", "fp32", 2, 128, 128, 4, 4, 64, grads=False)
     # (2) d x dtype x causal at the reference tests' odd shapes (tests/test_flash_attn.py:862-876)
     dense_case(ref, "bf16_d128_s128_causal", "bf16", 1, 128, 128, 2, 2, 128, causal=True)

@@ -4,7 +4,7 @@ and through the Python package (vllm_flash_attn -> vllm_flash_attn_2_cuda -> C A
 Checks: (1) the golden vectors (reference PyTorch oracle) with the reference tests' own rule
 max|out - out_ref| <= 2 * max|out_pt - out_ref| + 1e-5 (tests/test_flash_attn.py:1087);
 (2) the C oracle on seeded random inputs, to 2 ulp of the 16-bit output; (3) size-independent
-properties at BASELINE sizes."""
+properties at the benchmark configurations' full sizes."""
 import numpy as np
 import pytest
 import torch
@@ -258,7 +258,7 @@ def test_strided_inputs_and_out_arg():
 
 
 def test_headline_shape_slices_vs_oracle():
-    """BASELINE config 3 shape (b8 s4096 h32 d128 bf16 causal), reduced to b=1 (the kernel treats
+    """Headline configuration (b8 s4096 h32 d128 bf16 causal), reduced to b=1 (the kernel treats
     batch entries independently, checked above): two (head) slices against the oracle."""
     from oracle import fa_oracle
     from gpu_util import ulp_tol
@@ -280,7 +280,7 @@ def test_headline_shape_slices_vs_oracle():
 
 
 def test_decode_config5_shape_properties():
-    """BASELINE config 5 shape per GPU shard (b128 sq1 kv8192 h32/hk8 d128 fp16), reduced batch:
+    """Decode configuration per GPU shard (b128 sq1 kv8192 h32/hk8 d128 fp16), reduced batch:
     split vs unsplit agree, GQA folding equals the unfolded call, first batch entries vs oracle."""
     from oracle import fa_oracle
     from gpu_util import ulp_tol
@@ -319,7 +319,7 @@ def test_error_messages_match_reference():
 
 
 def test_config2_shape_slices_vs_oracle():
-    """BASELINE config 2 (b4 s2048 h16 d64 bf16 causal, fwd): head slices against the oracle."""
+    """Head-dim-64 forward configuration (b4 s2048 h16 d64 bf16 causal, fwd): head slices against the oracle."""
     from oracle import fa_oracle
     from gpu_util import ulp_tol
     torch.manual_seed(0)
@@ -334,7 +334,7 @@ def test_config2_shape_slices_vs_oracle():
 
 
 def test_config4_varlen_gqa_window_alibi():
-    """BASELINE config 4: flash_attn_varlen_func, GQA 32/8, d128 bf16, ragged seqlens up to 8192,
+    """Ragged configuration: flash_attn_varlen_func, GQA 32/8, d128 bf16, ragged seqlens up to 8192,
     causal + window (1024, 0) + ALiBi.  Full batch on the GPU; parity vs the oracle on the short
     sequences (all heads) and on one head of the longest sequences; a sequence computed alone is
     bitwise equal to its slice of the batched call."""

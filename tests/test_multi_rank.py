@@ -57,7 +57,7 @@ def test_shard_range_covers_and_balances():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
-    assert bench.shard_range(1024, 8, 3) == (384, 512)   # BASELINE config 5: 128 sequences per GPU
+    assert bench.shard_range(1024, 8, 3) == (384, 512)   # decode configuration: 128 sequences per GPU
 
 
 def test_two_ranks_gloo_sharded_equals_unsharded():

@@ -1,5 +1,5 @@
 """CPU tests: the C oracle against the golden vectors (generated from the reference's own PyTorch
-oracle, tests/golden/make_golden.py) and against torch SDPA (BASELINE config 1)."""
+oracle, tests/golden/make_golden.py) and against torch SDPA (the fp32 plumbing configuration)."""
 import numpy as np
 import pytest
 
@@ -145,7 +145,7 @@ def test_oracle_kvcache_vs_golden(name):
 
 
 def test_config1_fp32_vs_torch_sdpa():
-    """BASELINE config 1: batch=2 seqlen=128 nheads=4 headdim=64 fp32 non-causal vs torch SDPA."""
+    """Plumbing configuration: batch=2 seqlen=128 nheads=4 headdim=64 fp32 non-causal vs torch SDPA."""
     import torch
     import torch.nn.functional as F
     torch.manual_seed(0)
