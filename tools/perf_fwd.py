@@ -8,6 +8,8 @@ for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROO
 import torch
 import torch.nn.functional as F
 import cabi
+if os.environ.get("VFA_LIB"):  # A/B runs of two builds on one box
+    cabi.LIB_PATH = os.environ["VFA_LIB"]
 
 
 def timeit(fn, warm=5, it=20):

@@ -52,6 +52,32 @@ struct PrefillCfg {
     static_assert(TILE_CHUNKS % NT == 0, "tile must divide over threads");
 };
 
+// block -> (batch, head, m_block).  Blocks b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD whole (batch, kv-head) pairs: their K/V then stay in that XCD's L2 while the pair's
+// query heads and m-blocks stream through.  Heaviest m-blocks (causal) first.
+__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, int &bidb, int &bidh,
+                                          int &m_block) {
+    const int g = p.h_ratio;
+    const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
+    const int P = p.b * p.h_k;
+    const int L = blockIdx.x;
+    const int full = (P / 8) * 8 * W;
+    int pair, item;
+    if (L < full) {
+        const int x = L & 7, s = L >> 3;
+        pair = (s / W) * 8 + x;
+        item = s % W;
+    } else {
+        const int Lr = L - full;
+        pair = (P / 8) * 8 + Lr / W;
+        item = Lr % W;
+    }
+    bidb = pair / p.h_k;
+    const int hk = pair % p.h_k;
+    bidh = hk * g + item % g;
+    m_block = n_mblocks - 1 - item / g;
+}
+
 // FAST: K/V are contiguous per (batch, head) (no block table) and fit a 32-bit byte offset, so
 // tiles are fetched with buffer loads whose descriptor ends at the last valid key row: the key
 // tail and the head-dim padding read as zeros without any predication or 64-bit address
@@ -70,32 +96,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
 
-    // ---- block -> (batch, head, m_block).  Blocks b and b+8 share an XCD (round-robin
-    // dispatch), so give each XCD whole (batch, kv-head) pairs: their K/V then stay in that
-    // XCD's L2 while the pair's query heads and m-blocks stream through.  Heaviest m-blocks
-    // (causal) first. ----
     int bidb, bidh, m_block;
-    {
-        const int g = p.h_ratio;
-        const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
-        const int P = p.b * p.h_k;
-        const int L = blockIdx.x;
-        const int full = (P / 8) * 8 * W;
-        int pair, item;
-        if (L < full) {
-            const int x = L & 7, s = L >> 3;
-            pair = (s / W) * 8 + x;
-            item = s % W;
-        } else {
-            const int Lr = L - full;
-            pair = (P / 8) * 8 + Lr / W;
-            item = Lr % W;
-        }
-        bidb = pair / p.h_k;
-        const int hk = pair % p.h_k;
-        bidh = hk * g + item % g;
-        m_block = n_mblocks - 1 - item / g;
-    }
+    map_block(p, n_mblocks, bidb, bidh, m_block);
     const int hk = bidh / p.h_ratio;
 
     const BlockInfo bi(p, bidb);
@@ -289,22 +291,73 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
         // ---- S^T = K Q^T : s[kb2][reg] = score(key = n*64 + 32 kb2 + (reg&3) + 8 (reg>>2) + 4 hh,
         //                                      query = q0w + r) ----
+        // Vector instructions of a wave run in the shadow of its OWN MFMAs (not of those of the
+        // other wave on the SIMD), so softmax work is placed next to MFMAs it does not depend on:
+        // the maximum of the first 32 keys and the exponentials of the first 16, taken against the
+        // current reference point, go with the MFMAs of the second 32 keys.  They stand unless the
+        // tile needs a mask or moves the reference point (both rare), which redoes them.
+        bool need = has_alibi || (c0 + BN > sk);
+        if (p.is_causal || p.is_local) need = need || (c0 + BN > q0w + 1 + sk - sq + p.wr);
+        if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
         f32x16 s[2];
+        i32x4 pf[4];
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};  // four short row-sum chains instead of one of 32 adds
+        auto exp_step = [&](const int ks, const float mc_) __attribute__((always_inline)) {
+            const int b8 = 8 * (ks & 1);   // k-step ks = 16 keys = regs 8(ks&1).. of s[ks>>1]
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; kb2++) {
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < 4; w++) {
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks >> 1][b8 + 2 * w], c2, -mc_));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks >> 1][b8 + 2 * w + 1], c2, -mc_));
+                ps[w] += e0 + e1;
+                pf[ks][w] = pack2<BF16>(e0, e1);
+            }
+        };
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks]);
+            s[0] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[0]);
+        }
+        constexpr bool SPEC = DP >= 128;  // measured: +1..2 % at d = 128, -2.5 % at d = 64
+        const float mc_old = (m_run == -INFINITY ? 0.f : m_run) * c2;
+        float mx = -INFINITY;
+        if constexpr (!SPEC) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-                const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks] + 32 * kb2 * ROWB);
-                s[kb2] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[kb2]);
+                const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks] + 32 * ROWB);
+                s[1] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[1]);
+            }
+        } else {
+            // second 32 keys: MFMA ks, then a slice of the vector work on the first 32 keys, fenced
+            // so that the scheduler keeps each slice behind its MFMA; K fragments two steps ahead
+            i32x4 kf2[3];
+            kf2[0] = *(const i32x4 *)(kb + k_rd[0] + 32 * ROWB);
+            kf2[1] = *(const i32x4 *)(kb + k_rd[1] + 32 * ROWB);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                if (ks + 2 < KS) kf2[(ks + 2) % 3] = *(const i32x4 *)(kb + k_rd[ks + 2] + 32 * ROWB);
+                s[1] = mma32<BF16>(kf2[ks % 3], qf[ks], ks == 0 ? zero : s[1]);
+                if constexpr (!SPEC) continue;
+#pragma unroll
+                for (int j = ks * 16 / KS; j < (ks + 1) * 16 / KS; j++) mx = fmaxf(mx, s[0][j]);
+#pragma unroll
+                for (int pr = 0; pr < 8; pr++) {  // pair pr: k-step pr>>2, dword pr&3 of its P fragment
+                    if (pr * KS / 8 != ks) continue;
+                    const int st = pr >> 2, w = pr & 3, b8 = 8 * (st & 1);
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][b8 + 2 * w], c2, -mc_old));
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][b8 + 2 * w + 1], c2, -mc_old));
+                    ps[w] += e0 + e1;
+                    pf[st][w] = pack2<BF16>(e0, e1);
+                    // (keeps the slice here: LLVM would sink it to the block of its first use)
+                    asm volatile("" : "+v"(pf[st][w]), "+v"(ps[w]));
+                }
+                asm volatile("" : "+v"(mx));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         STAMP(1);
         // ---- masks and ALiBi, only where needed (mask.h:128-209) ----
-        bool need = has_alibi || (c0 + BN > sk);
-        if (p.is_causal || p.is_local) need = need || (c0 + BN > q0w + 1 + sk - sq + p.wr);
-        if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
         if (need) {
             const int row = q0w + r;
             const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
@@ -320,12 +373,18 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                                         : x - alibi * fabsf((float)(row + sk - sq - col));
                     s[kb2][j] = (col >= lo && col < hi) ? x : -INFINITY;
                 }
+            if constexpr (SPEC) {
+                mx = s[0][0];
+#pragma unroll
+                for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
+            }
+        }
+        if constexpr (!SPEC) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) mx = fmaxf(mx, s[0][j]);
         }
 
         // ---- online softmax (softmax.h:135-166), one query row per lane ----
-        float mx = s[0][0];
-#pragma unroll
-        for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
 #pragma unroll
         for (int j = 0; j < 16; j++) mx = fmaxf(mx, s[1][j]);
         mx = half_swap_max(mx);
@@ -347,32 +406,26 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         }
         m_run = m_new;
         const float mc = m_cur * c2;
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};  // four short chains instead of one of 32 dependent adds
+        if constexpr (SPEC) {
+            if (need || upd) {  // the early exponentials were taken on unmasked scores or an old reference
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; kb2++)
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb2][j], c2, -mc));
-                s[kb2][j] = e;
-                ps[j & 3] += e;
+                for (int w = 0; w < 4; w++) ps[w] = 0.f;
+                exp_step(0, mc);
+                exp_step(1, mc);
             }
-        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        } else {
+            exp_step(0, mc);
+        }
 
         STAMP(2);
         // ---- O^T += V^T P^T.  P fragment of k-step ks (16 keys) = regs 8(ks&1).. of s[ks>>1];
         // element j of lane half hh is key 16 ks + 8 (j>>2) + 4 hh + (j&3). ----
-        i32x4 pf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            const int b8 = 8 * (ks & 1);
+            if constexpr (SPEC) { if (ks < 2) exp_step(ks + 2, mc); }  // next to the MFMAs of k-step ks
+            else { if (ks < 3) exp_step(ks + 1, mc); }
 #pragma unroll
-            for (int w = 0; w < 4; w++)
-                pf[ks][w] = pack2<BF16>(s[ks >> 1][b8 + 2 * w], s[ks >> 1][b8 + 2 * w + 1]);
-        }
-#pragma unroll
-        for (int db = 0; db < NDB; db++) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
+            for (int db = 0; db < NDB; db++) {
                 const s16x4 v0 = lds_read_tr16(vb + v_rd[db][0] + 16 * ks * ROWB);
                 const s16x4 v1 = lds_read_tr16(vb + v_rd[db][1] + 16 * ks * ROWB);
                 i32x4 vf;
@@ -381,6 +434,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 o[db] = mma32<BF16>(vf, pf[ks], o[db]);
             }
         }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         STAMP(3);
         }  // !skip
 
