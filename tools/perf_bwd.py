@@ -7,6 +7,8 @@ for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROO
 import ctypes as C
 import torch
 import cabi
+if os.environ.get("VFA_LIB"):  # A/B runs of two builds on one box
+    cabi.LIB_PATH = os.environ["VFA_LIB"]
 import bench
 
 
