@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(NT, 1) k(unsigned long long *out, float *sink,
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { out[threadIdx.x >> 6] = t1 - t0; out[8 + (threadIdx.x >> 6)] = t0; out[16 + (threadIdx.x >> 6)] = t1; }
     float s = 0;
     for (int j = 0; j < 16; j++) s += c0[j];
     for (int j = 0; j < 8; j++) s += x[j];
@@ -40,17 +40,19 @@ static void run(unsigned long long *d, float *sink) {
         k<NF, NT><<<256, NT>>>(d, sink, 0.37f);
         hipDeviceSynchronize();
     }
-    unsigned long long h;
-    hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
-    printf("%d waves/SIMD, %d fillers per MFMA gap: %7.1f cycles per 32 MFMAs (+%d VALU)\n", NT / 256, NF,
-           (double)h / 64, 32 * NF);
+    unsigned long long h[24];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    unsigned long long tmin = h[8], tmax = h[16];
+    for (int w = 0; w < NT / 64; w++) { if (h[8 + w] < tmin) tmin = h[8 + w]; if (h[16 + w] > tmax) tmax = h[16 + w]; }
+    printf("%d waves/SIMD, %d fillers per MFMA gap: wave 0 %7.1f, wave %d %7.1f, first start to last end %7.1f cycles per 32 MFMAs of each wave (+%d VALU)\n",
+           NT / 256, NF, (double)h[0] / 64, NT / 64 - 1, (double)h[NT / 64 - 1] / 64, (double)(tmax - tmin) / 64, 32 * NF);
 }
 
 int main() {
     unsigned long long *d; float *sink;
-    hipMalloc(&d, 16); hipMalloc(&sink, 8);
+    hipMalloc(&d, 24 * 8); hipMalloc(&sink, 8);
     run<0, 256>(d, sink); run<2, 256>(d, sink); run<4, 256>(d, sink); run<5, 256>(d, sink);
     run<6, 256>(d, sink); run<8, 256>(d, sink);
-    run<0, 512>(d, sink); run<2, 512>(d, sink); run<4, 512>(d, sink); run<6, 512>(d, sink);
+    run<0, 512>(d, sink); run<2, 512>(d, sink); run<4, 512>(d, sink); run<5, 512>(d, sink); run<6, 512>(d, sink); run<8, 512>(d, sink);
     return 0;
 }
