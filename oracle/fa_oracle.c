@@ -187,6 +187,70 @@ static void append_kv(fa_oracle_params *p) {
     }
 }
 
+/* philox.cuh:22-29: one Philox-4x32 round. */
+static void philox_round(uint32_t c[4], const uint32_t key[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0]; /* kPhiloxSA * ctr.x */
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2]; /* kPhiloxSB * ctr.z */
+    const uint32_t r0 = (uint32_t)(p1 >> 32) ^ c[1] ^ key[0];
+    const uint32_t r1 = (uint32_t)p1;
+    const uint32_t r2 = (uint32_t)(p0 >> 32) ^ c[3] ^ key[1];
+    const uint32_t r3 = (uint32_t)p0;
+    c[0] = r0; c[1] = r1; c[2] = r2; c[3] = r3;
+}
+
+/* philox.cuh:31-49: counter = (offset, subsequence), key = seed; n_rounds - 1 rounds each followed
+ * by a key bump, then one more round.  The reference runs 7 rounds in all. */
+void fa_oracle_philox(uint64_t seed, uint64_t subsequence, uint64_t offset, int n_rounds,
+                      uint32_t out[4]) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)subsequence,
+                     (uint32_t)(subsequence >> 32)};
+    for (int i = 0; i < n_rounds - 1; i++) {
+        philox_round(c, key);
+        key[0] += 0x9E3779B9u;
+        key[1] += 0xBB67AE85u;
+    }
+    philox_round(c, key);
+    for (int i = 0; i < 4; i++) out[i] = c[i];
+}
+
+/* Which random byte decides entry (row, col).  The reference draws one 128-bit Philox value per
+ * thread per 16 x 32 block of the attention matrix (dropout.h:39-44: subsequence = (row / 16,
+ * col / 32), offset + (bid * nheads + hid) * 32 + lane, dropout.h:21) and spends its 16 bytes on
+ * the 16 entries the thread holds of that block in the m16n8k16 accumulator layout: lane t owns
+ * rows t/4 and t/4 + 8, columns 2 (t%4) + {0, 1} of each of the four 8-column atoms; byte
+ * j*8 + a*4 + v (dropout.h:46,59-63,79 with the (4,2) regrouping of utils.h:215-223) goes to atom
+ * 2j + a, value v = 2 (row >= 8) + (col & 1).  An entry is kept iff byte <= keep_u8 (:69,79). */
+int fa_oracle_dropout_keep(uint64_t seed, uint64_t offset, int bid, int hid, int nheads, int row,
+                           int col, int keep_u8) {
+    const int r16 = row & 15, c32 = col & 31;
+    const int lane = (r16 & 7) * 4 + (c32 & 7) / 2;
+    const int atom = c32 >> 3;
+    const int v = 2 * (r16 >> 3) + (c32 & 1);
+    const int byte_idx = (atom >> 1) * 8 + (atom & 1) * 4 + v;
+    const uint64_t subseq = (uint64_t)(uint32_t)(row >> 4) | ((uint64_t)(uint32_t)(col >> 5) << 32);
+    const uint64_t off = offset + (uint64_t)((bid * nheads + hid) * 32 + lane);
+    uint32_t rnd[4];
+    fa_oracle_philox(seed, subseq, off, 7, rnd);
+    const int byte = (rnd[byte_idx >> 2] >> (8 * (byte_idx & 3))) & 0xff;
+    return byte <= keep_u8;
+}
+
+/* flash_api.cpp:106,111 */
+static int keep_threshold(float p_dropout) { return (int)(uint8_t)floor((1.f - p_dropout) * 255.0); }
+
+void fa_oracle_dropout_mask(uint64_t seed, uint64_t offset, int b, int h, int seqlen_q,
+                            int seqlen_k, float p_dropout, uint8_t *mask) {
+    const int thr = keep_threshold(p_dropout);
+#pragma omp parallel for collapse(2)
+    for (int bb = 0; bb < b; bb++)
+        for (int hh = 0; hh < h; hh++)
+            for (int i = 0; i < seqlen_q; i++)
+                for (int j = 0; j < seqlen_k; j++)
+                    mask[(((size_t)bb * h + hh) * seqlen_q + i) * seqlen_k + j] =
+                        (uint8_t)fa_oracle_dropout_keep(seed, offset, bb, hh, h, i, j, thr);
+}
+
 typedef struct {
     int is_causal, is_local, wl, wr;
     float scale, scale_log2;
@@ -231,6 +295,9 @@ static void tile_pass(const fa_oracle_params *p, const mask_cfg *mc, const block
     if (p->alibi_slopes) /* flash_fwd_kernel.h:266: slope / scale_softmax, added pre-scale */
         alibi = p->alibi_slopes[(int64_t)bidb * p->alibi_batch_stride + bidh] / mc->scale;
 
+    const int drop = p->p_dropout > 0.f;
+    const int keep_u8 = keep_threshold(p->p_dropout);
+    const float rp_dropout = 1.f / (1.f - p->p_dropout); /* flash_api.cpp:112 */
     float s[256];
     for (int r = 0; r < rows; r++) {
         const int row_idx = m_block * BM + r;
@@ -280,6 +347,16 @@ static void tile_pass(const fa_oracle_params *p, const mask_cfg *mc, const block
                 row_sum += pj;                                        /* fp32 P: softmax.h:164 */
                 s[j] = fa_oracle_round(pj, p->round_mode);            /* flash_fwd_kernel.h:323 */
             }
+            if (drop || p->s_dmask) { /* flash_fwd_kernel.h:324-337: on the ROUNDED P, after the row sum */
+                for (int j = 0; j < BN; j++) {
+                    const int keep = !drop || fa_oracle_dropout_keep(p->philox_seed, p->philox_offset,
+                                                                     bidb, bidh, p->h, row_idx, c0 + j, keep_u8);
+                    if (p->s_dmask && j < cn) /* sign bit = dropped (dropout.h:31-33) */
+                        p->s_dmask[(((int64_t)bidb * p->h + bidh) * p->seqlen_q_rounded + row_idx) *
+                                       p->seqlen_k_rounded + c0 + j] = keep ? s[j] : -s[j];
+                    if (!keep) s[j] = 0.f;
+                }
+            }
             for (int j = 0; j < cn; j++) { /* V tail rows are zero-filled: kernel.h:291-294 */
                 if (s[j] == 0.f) continue;
                 const float *vr = kv_row(p, p->v, bi, bidb, hk, c0 + j);
@@ -289,7 +366,8 @@ static void tile_pass(const fa_oracle_params *p, const mask_cfg *mc, const block
         }
         /* softmax.h:168-185 */
         const int bad = (row_sum == 0.f || row_sum != row_sum);
-        const float inv = bad ? 1.f : 1.f / row_sum;
+        const float inv_sum = bad ? 1.f : 1.f / row_sum;
+        const float inv = drop ? inv_sum * rp_dropout : inv_sum; /* softmax.h:181 */
         lse_rows[r] = bad ? empty_lse : row_max * mc->scale + logf(row_sum);
         for (int c = 0; c < d; c++) o_rows[r * d + c] = acc[c] * inv;
     }
@@ -372,7 +450,11 @@ int fa_oracle_fwd(fa_oracle_params *p) {
  * its boundary is pinned by vllm_flash_attn/flash_attn_interface.py:135-154 and the parameter
  * block csrc/flash_attn/src/flash.h:145-183.  Math: P = exp2(S*scale_log2 - LSE*log2e) with the
  * forward's mask/bias, dV += P16^T dO, dP = dO V^T, delta = rowsum(dO*O), dS = P*(dP - delta),
- * dQ += scale * dS16 K, dK += scale * dS16^T Q; dK/dV of a KV head sum over its query heads. */
+ * dQ += scale * dS16 K, dK += scale * dS16^T Q; dK/dV of a KV head sum over its query heads.
+ * With dropout (keep mask M, keep probability pk, the forward's Philox stream): dV uses P16 * M,
+ * delta is scaled by pk, dS = P * (M * dP - pk * delta), and dQ, dK (dV) carry the factor
+ * scale / pk (1 / pk) at the end -- the scale_softmax_rp_dropout / rp_dropout fields of
+ * flash.h:109-117 (the upstream FlashAttention-2 backward formulation). */
 int fa_oracle_bwd(fa_oracle_params *p) {
     if (p->d > MAXD || p->h % p->h_k != 0) return -1;
     mask_cfg mc;
@@ -383,6 +465,11 @@ int fa_oracle_bwd(fa_oracle_params *p) {
     mc.scale = p->softmax_scale;
     mc.scale_log2 = p->softmax_scale * LOG2E;
     const int d = p->d, g = p->h / p->h_k;
+    const int drop = p->p_dropout > 0.f;
+    const int keep_u8 = keep_threshold(p->p_dropout);
+    const float p_keep = 1.f - p->p_dropout;
+    const float rp_dropout = 1.f / p_keep;
+    const float scale_rp = drop ? rp_dropout * mc.scale : mc.scale; /* flash_api.cpp:113 */
 
 #pragma omp parallel for collapse(2) schedule(dynamic)
     for (int b = 0; b < p->b; b++) {
@@ -404,6 +491,7 @@ int fa_oracle_bwd(fa_oracle_params *p) {
                     const float lse = p->lse[((int64_t)b * p->h + h) * p->seqlen_q + i];
                     float delta = 0.f;
                     for (int c = 0; c < d; c++) delta += dor[c] * orow[c];
+                    if (drop) delta *= p_keep;
                     if (p->softmax_d)
                         p->softmax_d[((int64_t)b * p->h + h) * p->seqlen_q + i] = delta;
                     float dqa[MAXD];
@@ -423,8 +511,10 @@ int fa_oracle_bwd(fa_oracle_params *p) {
                                 else a -= alibi * fabsf((float)(i + sk - sq - j));
                             }
                             float pj = exp2f(a * mc.scale_log2 - lse * LOG2E);
-                            float ds = pj * (dp - delta);
-                            float p16 = fa_oracle_round(pj, p->round_mode);
+                            const int keep = !drop || fa_oracle_dropout_keep(p->philox_seed, p->philox_offset,
+                                                                             b, h, p->h, i, j, keep_u8);
+                            float ds = pj * ((keep ? dp : 0.f) - delta);
+                            float p16 = keep ? fa_oracle_round(pj, p->round_mode) : 0.f;
                             float ds16 = fa_oracle_round(ds, p->round_mode);
                             float *dkr = dkacc + (size_t)j * d, *dvr = dvacc + (size_t)j * d;
                             for (int c = 0; c < d; c++) {
@@ -435,15 +525,16 @@ int fa_oracle_bwd(fa_oracle_params *p) {
                         }
                     }
                     for (int c = 0; c < d; c++)
-                        dqr[c] = fa_oracle_round(dqa[c] * mc.scale, p->round_mode);
+                        dqr[c] = fa_oracle_round(dqa[c] * scale_rp, p->round_mode);
                 }
             }
             for (int j = 0; j < sk; j++) {
                 float *dkr = kv_row(p, p->dk, &bi, b, hk, j);
                 float *dvr = kv_row(p, p->dv, &bi, b, hk, j);
                 for (int c = 0; c < d; c++) {
-                    dkr[c] = fa_oracle_round(dkacc[(size_t)j * d + c] * mc.scale, p->round_mode);
-                    dvr[c] = fa_oracle_round(dvacc[(size_t)j * d + c], p->round_mode);
+                    dkr[c] = fa_oracle_round(dkacc[(size_t)j * d + c] * scale_rp, p->round_mode);
+                    dvr[c] = fa_oracle_round(drop ? dvacc[(size_t)j * d + c] * rp_dropout
+                                                  : dvacc[(size_t)j * d + c], p->round_mode);
                 }
             }
             free(dkacc);

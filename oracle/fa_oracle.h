@@ -63,6 +63,16 @@ typedef struct fa_oracle_params {
     const float *rotary_cos, *rotary_sin; /* (seqlen_ro, rotary_dim/2) or NULL */
     int rotary_dim;
     int is_rotary_interleaved;
+    /* Dropout (dropout.h:12-92, philox.cuh:12-49; compiled out of the fork, setup.py:204, but part
+     * of the Python signatures).  p_dropout = probability of DROPPING (the user value); the Philox
+     * seed / offset are what the generator handed out (flash_api.cpp:388-394). */
+    float p_dropout;
+    uint64_t philox_seed, philox_offset;
+    /* Return_softmax output (flash_fwd_kernel.h:326-334): (b, h, seqlen_q_rounded, seqlen_k_rounded),
+     * 16-bit-rounded exp(S - running max) with the sign bit set on dropped entries; NULL = off.
+     * Only entries of visited tiles with row < seqlen_q and col < seqlen_k are written. */
+    float *s_dmask;
+    int seqlen_q_rounded, seqlen_k_rounded;
 } fa_oracle_params;
 
 /* flash_api.cpp:289-294,121-124: window clamp, causal fold, one-sided fill. */
@@ -80,6 +90,19 @@ int fa_oracle_fwd(fa_oracle_params *p);
 int fa_oracle_bwd(fa_oracle_params *p);
 
 float fa_oracle_round(float x, int round_mode);
+
+/* philox.cuh:31-49 with the round count as a parameter (the reference runs 7): out = 4 words. */
+void fa_oracle_philox(uint64_t seed, uint64_t subsequence, uint64_t offset, int n_rounds,
+                      uint32_t out[4]);
+
+/* dropout.h:17-23,39-79 + flash_fwd_kernel.h:324-325: 1 if attention entry (row, col) of
+ * (batch bid, head hid) is KEPT.  keep_u8 = floor((1 - p_dropout) * 255) (flash_api.cpp:111). */
+int fa_oracle_dropout_keep(uint64_t seed, uint64_t offset, int bid, int hid, int nheads, int row,
+                           int col, int keep_u8);
+
+/* Whole keep mask, (b, h, seqlen_q, seqlen_k) bytes. */
+void fa_oracle_dropout_mask(uint64_t seed, uint64_t offset, int b, int h, int seqlen_q,
+                            int seqlen_k, float p_dropout, uint8_t *mask);
 
 #ifdef __cplusplus
 }

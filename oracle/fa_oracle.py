@@ -36,6 +36,8 @@ class _Params(C.Structure):
         ("knew", C.c_void_p), ("vnew", C.c_void_p), ("seqlen_knew", C.c_int),
         ("rotary_cos", C.c_void_p), ("rotary_sin", C.c_void_p), ("rotary_dim", C.c_int),
         ("is_rotary_interleaved", C.c_int),
+        ("p_dropout", C.c_float), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
+        ("s_dmask", C.c_void_p), ("seqlen_q_rounded", C.c_int), ("seqlen_k_rounded", C.c_int),
     ]
 
 
@@ -62,6 +64,11 @@ def lib():
         _lib.fa_oracle_round.argtypes = [C.c_float, C.c_int]
         _lib.fa_oracle_num_splits_heuristic.argtypes = [C.c_int] * 4
         _lib.fa_oracle_fold_window.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
+        _lib.fa_oracle_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        _lib.fa_oracle_philox.restype = None
+        _lib.fa_oracle_dropout_keep.argtypes = [C.c_uint64, C.c_uint64] + [C.c_int] * 6
+        _lib.fa_oracle_dropout_mask.argtypes = [C.c_uint64, C.c_uint64] + [C.c_int] * 4 + [C.c_float, C.c_void_p]
+        _lib.fa_oracle_dropout_mask.restype = None
     return _lib
 
 
@@ -86,6 +93,24 @@ def fold_window(seqlen_q, seqlen_k, has_alibi, causal, window):
 
 def num_splits_heuristic(batch_nheads_mblocks, num_sms, num_n_blocks, max_splits=128):
     return lib().fa_oracle_num_splits_heuristic(batch_nheads_mblocks, num_sms, num_n_blocks, max_splits)
+
+
+def philox(seed, subsequence, offset, n_rounds=7):
+    """Four 32-bit words of Philox-4x32 with counter (offset, subsequence) and key seed."""
+    out = np.zeros(4, dtype=np.uint32)
+    lib().fa_oracle_philox(seed, subsequence, offset, n_rounds, out.ctypes.data)
+    return out
+
+
+def dropout_mask(seed, offset, b, h, seqlen_q, seqlen_k, p_dropout):
+    """Keep mask (b, h, seqlen_q, seqlen_k) bool of the reference's dropout for this Philox state."""
+    m = np.zeros((b, h, seqlen_q, seqlen_k), dtype=np.uint8)
+    lib().fa_oracle_dropout_mask(seed, offset, b, h, seqlen_q, seqlen_k, float(p_dropout), m.ctypes.data)
+    return m.astype(bool)
+
+
+def _round128(x):
+    return (int(x) + 127) // 128 * 128
 
 
 def _common(p, keep, q, k, v, dtype, softmax_scale, causal, window, alibi_slopes, cu_seqlens_q,
@@ -141,9 +166,11 @@ def attention_fwd(q, k, v, *, dtype="fp32", softmax_scale=None, causal=False, wi
                   alibi_slopes=None, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=None,
                   max_seqlen_k=None, seqused_k=None, cache_seqlens=None, block_table=None,
                   cache_batch_idx=None, knew=None, vnew=None, rotary_cos=None, rotary_sin=None,
-                  rotary_interleaved=True, num_splits=1, block_m=0, block_n=0):
-    """Returns (out, lse[, k_cache, v_cache]).  out like q (float32 holding dtype-rounded values);
-    lse (b, h, seqlen_q).  With knew/vnew the caches are updated on copies that are returned."""
+                  rotary_interleaved=True, num_splits=1, block_m=0, block_n=0, p_dropout=0.0,
+                  philox_seed=0, philox_offset=0, return_softmax=False):
+    """Returns (out, lse[, k_cache, v_cache][, s_dmask]).  out like q (float32 holding dtype-rounded
+    values); lse (b, h, seqlen_q).  With knew/vnew the caches are updated on copies that are
+    returned.  With return_softmax, s_dmask (b, h, seqlen_q_rounded, seqlen_k_rounded) is appended."""
     q, k, v = _f32(q), _f32(k), _f32(v)
     append = knew is not None
     if append:
@@ -166,17 +193,22 @@ def attention_fwd(q, k, v, *, dtype="fp32", softmax_scale=None, causal=False, wi
             p.rotary_cos, p.rotary_sin = _ptr(rc), _ptr(rs)
             p.rotary_dim = rc.shape[1] * 2
             p.is_rotary_interleaved = int(rotary_interleaved)
+    p.p_dropout, p.philox_seed, p.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)
+    sdm = None
+    if return_softmax:
+        p.seqlen_q_rounded, p.seqlen_k_rounded = _round128(p.seqlen_q), _round128(p.seqlen_k)
+        sdm = np.zeros((b, h, p.seqlen_q_rounded, p.seqlen_k_rounded), dtype=np.float32)
+        p.s_dmask = _ptr(sdm)
     rc_ = lib().fa_oracle_fwd(C.byref(p))
     if rc_ != 0:
         raise RuntimeError(f"fa_oracle_fwd failed: {rc_}")
-    if append:
-        return out, lse, k, v
-    return out, lse
+    res = (out, lse, k, v) if append else (out, lse)
+    return res + (sdm,) if return_softmax else res
 
 
 def attention_bwd(dout, q, k, v, out, lse, *, dtype="fp32", softmax_scale=None, causal=False,
                   window=(-1, -1), alibi_slopes=None, cu_seqlens_q=None, cu_seqlens_k=None,
-                  max_seqlen_q=None, max_seqlen_k=None):
+                  max_seqlen_q=None, max_seqlen_k=None, p_dropout=0.0, philox_seed=0, philox_offset=0):
     """Returns (dq, dk, dv, softmax_d)."""
     dout, q, k, v, out, lse = (_f32(x) for x in (dout, q, k, v, out, lse))
     p, keep = _Params(), []
@@ -187,6 +219,7 @@ def attention_bwd(dout, q, k, v, out, lse, *, dtype="fp32", softmax_scale=None, 
     sd = np.zeros((b, h, sq), dtype=np.float32)
     p.q, p.k, p.v, p.out, p.lse, p.dout = (_ptr(x) for x in (q, k, v, out, lse, dout))
     p.dq, p.dk, p.dv, p.softmax_d = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(sd)
+    p.p_dropout, p.philox_seed, p.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)
     rc_ = lib().fa_oracle_bwd(C.byref(p))
     if rc_ != 0:
         raise RuntimeError(f"fa_oracle_bwd failed: {rc_}")

@@ -132,6 +132,52 @@ def dense_case(ref, name, dtype, b, sq, sk, h, hk, d, causal=False, window=(-1, 
     print(f"{name}: err_out_pt={data['err_out_pt']:.3e}")
 
 
+def dropout_case(ref, name, dtype, b, sq, sk, h, hk, d, p_dropout, philox_seed, philox_offset,
+                 causal=False, window=(-1, -1), alibi=False, seed=0):
+    """Dropout: the keep mask is the reference kernel's Philox pattern (dropout.h / philox.cuh) as
+    restated by oracle/fa_oracle.c for (philox_seed, philox_offset); the expected outputs and
+    gradients come from the reference's attention_ref(dropout_p, dropout_mask).  This pins the
+    dropout MATH given the mask; the Philox core is pinned separately (philox_aten.json)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT_DIR)))
+    from oracle import fa_oracle
+    torch.manual_seed(seed)
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    q = torch.randn(b, sq, h, d).to(tdt)
+    k = torch.randn(b, sk, hk, d).to(tdt)
+    v = torch.randn(b, sk, hk, d).to(tdt)
+    g = torch.randn(b, sq, h, d).to(tdt)
+    slopes = bias = None
+    if alibi:
+        slopes = torch.rand(b, h, dtype=torch.float32) * 0.3
+        bias = ref.attn_bias_from_alibi_slopes(slopes, sq, sk, None, None, causal=causal)
+    mask_np = fa_oracle.dropout_mask(philox_seed, philox_offset, b, h, sq, sk, p_dropout)
+    mask = torch.from_numpy(mask_np)
+    q32, k32, v32 = (x.float().clone().requires_grad_() for x in (q, k, v))
+    o32, _ = ref.attention_ref(q32, k32, v32, None, None, bias, p_dropout, mask, causal=causal,
+                               window_size=window, upcast=True)
+    dq, dk, dv = torch.autograd.grad(o32, (q32, k32, v32), g.float())
+    qp, kp, vp = (x.clone().requires_grad_() for x in (q, k, v))
+    opt, _ = ref.attention_ref(qp, kp, vp, None, None, bias, p_dropout, mask, causal=causal,
+                               window_size=window, upcast=False, reorder_ops=True)
+    dqp, dkp, dvp = torch.autograd.grad(opt, (qp, kp, vp), g)
+    data = dict(q=to_bits(q), k=to_bits(k), v=to_bits(v), g=to_bits(g),
+                keep_mask=np.packbits(mask_np), out_ref=o32.detach().numpy(),
+                lse_ref=ref_lse(ref, q, k, causal, window, bias).numpy(),
+                err_out_pt=np.float32((opt.float() - o32).abs().max().item()),
+                dq_ref=dq.numpy(), dk_ref=dk.numpy(), dv_ref=dv.numpy(),
+                err_dq_pt=np.float32((dqp.float() - dq).abs().max().item()),
+                err_dk_pt=np.float32((dkp.float() - dk).abs().max().item()),
+                err_dv_pt=np.float32((dvp.float() - dv).abs().max().item()))
+    if slopes is not None:
+        data["alibi_slopes"] = slopes.numpy()
+    meta = dict(name=name, kind="dropout", dtype=dtype, b=b, sq=sq, sk=sk, h=h, hk=hk, d=d,
+                causal=causal, window=list(window), alibi=alibi, seed=seed, p_dropout=p_dropout,
+                philox_seed=philox_seed, philox_offset=philox_offset)
+    data["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **data)
+    print(f"{name}: err_out_pt={data['err_out_pt']:.3e} keep={mask_np.mean():.4f}")
+
+
 def kvcache_case(ref, name, dtype, b, sq, sk, h, hk, d, causal, page, seed=0, alibi=False,
                  window=(-1, -1)):
     """Read-only kv-cache decode: cache_seqlens < capacity; optional paged cache."""
@@ -171,8 +217,21 @@ def kvcache_case(ref, name, dtype, b, sq, sk, h, hk, d, causal, page, seed=0, al
     print(f"{name}: err_out_pt={data['err_out_pt']:.3e}")
 
 
+def dropout_cases(ref):
+    # dropout_p = 0.17 is the reference tests' value (tests/test_flash_attn.py:549,662,850)
+    dropout_case(ref, "drop_bf16_d128_s128_causal", "bf16", 2, 128, 128, 2, 2, 128, 0.17, 0, 0, causal=True)
+    dropout_case(ref, "drop_fp16_d64_113x203_full", "fp16", 1, 113, 203, 2, 2, 64, 0.17, 1234567, 96)
+    dropout_case(ref, "drop_bf16_d128_gqa_local", "bf16", 1, 200, 263, 4, 2, 128, 0.3, 42, 1 << 33,
+                 window=(57, 21))
+    dropout_case(ref, "drop_fp16_d32_alibi_causal", "fp16", 2, 96, 160, 2, 1, 32, 0.5, 7, 64,
+                 causal=True, alibi=True)
+
+
 def main():
     ref = load_reference_oracle()
+    if len(sys.argv) > 1 and sys.argv[1] == "--dropout-only":
+        return dropout_cases(ref)
+    dropout_cases(ref)
     # (1) plumbing configuration: fp32, also checked against torch SDPA in the test
     dense_case(ref, "c1_fp32_b2_s128_h4_d64", "fp32", 2, 128, 128, 4, 4, 64, grads=False)
     # (2) d x dtype x causal at the reference tests' odd shapes (tests/test_flash_attn.py:862-876)

@@ -21,7 +21,8 @@ def golden_names(kind=None):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     if kind is None:
         return names
-    return [n for n in names if (n.startswith("kvc_")) == (kind == "kvcache")]
+    kind_of = lambda n: "kvcache" if n.startswith("kvc_") else ("dropout" if n.startswith("drop_") else "dense")
+    return [n for n in names if kind_of(n) == kind]
 
 
 def load_golden(name):
