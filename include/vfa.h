@@ -61,7 +61,9 @@ typedef struct vfa_params {
     const int32_t *cache_batch_idx;  /* (b) or NULL */
     const float *alibi_slopes;       /* (h) or (b, h) fp32, or NULL */
     int64_t alibi_slopes_batch_stride; /* 0 for (h) */
-    float p_dropout;                 /* must be 0 (dropout is compiled out of the reference fork) */
+    float p_dropout;                 /* probability of DROPPING an attention entry, in [0, 1); > 0 only
+                                        for vfa_mha_fwd / vfa_mha_varlen_fwd (no split, no paging) and
+                                        the backward entry points (flash_api.cpp:105-117) */
     float softmax_scale;
     int is_causal;
     int window_size_left, window_size_right;   /* raw user values; folded as flash_api.cpp:289-294 */
@@ -95,6 +97,19 @@ typedef struct vfa_params {
      * after the main kernel and after the dq conversion kernel, so a caller can time the main
      * kernel alone.  No counterpart in the reference. */
     void **stage_events;
+    /* Dropout (csrc/flash_attn/src/dropout.h:12-92, philox.cuh:12-49; flash_api.cpp:379-394).
+     * Forward: the Philox seed / offset the caller's generator handed out (the offset must then
+     * advance by b * h * 32); if rng_state != NULL the kernel also writes {seed, offset} there
+     * (2 x uint64 on the device, flash_fwd_kernel.h:51-54).  Backward: rng_state != NULL is READ on
+     * the device for {seed, offset} (what the forward wrote), else philox_seed / philox_offset. */
+    uint64_t philox_seed, philox_offset;
+    uint64_t *rng_state;
+    /* Return_softmax output (flash_fwd_kernel.h:326-334), forward with p_dropout > 0 only: 16-bit
+     * (b, h, seqlen_q_rounded, seqlen_k_rounded), exp(score - running max) per 64-key tile with
+     * the sign bit set on dropped entries; NULL = off.  Both rounded lengths are multiples of 128
+     * (flash_api.cpp:339-340,353).  For testing, like the reference's. */
+    void *s_dmask;
+    int seqlen_q_rounded, seqlen_k_rounded;
 } vfa_params;
 
 /* Forward, dense batch.  Replaces mha_fwd, csrc/flash_attn/flash_api.cpp:240-420

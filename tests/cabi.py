@@ -40,6 +40,8 @@ class VfaParams(C.Structure):
         ("deterministic", _int),
         ("stream", _p),
         ("stage_events", _p),
+        ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64), ("rng_state", _p),
+        ("s_dmask", _p), ("seqlen_q_rounded", _int), ("seqlen_k_rounded", _int),
     ]
 
 
@@ -100,9 +102,10 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
         cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, seqused_k=None,
         cache_seqlens=None, cache_batch_idx=None, block_table=None, knew=None, vnew=None,
         rotary_cos=None, rotary_sin=None, rotary_interleaved=True, num_splits=1, kvcache=False,
-        out=None):
-    """Forward through the C ABI on torch CUDA tensors.  Returns (out, lse).  Picks the entry point
-    like the reference's Python layer does: varlen if cu_seqlens_q, kvcache if asked, else fwd."""
+        out=None, p_dropout=0.0, philox_seed=0, philox_offset=0, return_softmax=False, rng_state=None):
+    """Forward through the C ABI on torch CUDA tensors.  Returns (out, lse), plus s_dmask
+    (b, h, seqlen_q_rounded, seqlen_k_rounded) with return_softmax.  Picks the entry point like the
+    reference's Python layer does: varlen if cu_seqlens_q, kvcache if asked, else fwd."""
     import torch
     P = VfaParams()
     keep = []
@@ -165,18 +168,27 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
             P.rotary_dim = rotary_cos.shape[1] * 2
             P.is_rotary_interleaved = int(rotary_interleaved)
     P.stream = _stream()
+    P.p_dropout, P.philox_seed, P.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)
+    if rng_state is not None:
+        P.rng_state = rng_state.data_ptr()
+    sdm = None
+    if return_softmax:
+        r128 = lambda x: (x + 127) // 128 * 128
+        sdm = torch.zeros(b, h, r128(sq), r128(sk), dtype=q.dtype, device=q.device)
+        P.s_dmask, P.seqlen_q_rounded, P.seqlen_k_rounded = sdm.data_ptr(), r128(sq), r128(sk)
     if varlen:
         call("vfa_mha_varlen_fwd", P)
     elif kvcache or cache_seqlens is not None or paged or knew is not None or cache_batch_idx is not None:
         call("vfa_mha_fwd_kvcache", P)
     else:
         call("vfa_mha_fwd", P)
-    return out, lse
+    return (out, lse, sdm) if return_softmax else (out, lse)
 
 
 def bwd(dout, q, k, v, out, lse, *, softmax_scale=None, causal=False, window=(-1, -1),
         alibi_slopes=None, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=None,
-        max_seqlen_k=None, deterministic=False):
+        max_seqlen_k=None, deterministic=False, p_dropout=0.0, philox_seed=0, philox_offset=0,
+        rng_state=None):
     """Backward through the C ABI.  Returns (dq, dk, dv, softmax_d)."""
     import torch
     P = VfaParams()
@@ -215,5 +227,8 @@ def bwd(dout, q, k, v, out, lse, *, softmax_scale=None, causal=False, window=(-1
         P.dk_accum, P.dv_accum = dka.data_ptr(), dva.data_ptr()
     P.deterministic = int(deterministic)
     P.stream = _stream()
+    P.p_dropout, P.philox_seed, P.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)
+    if rng_state is not None:
+        P.rng_state = rng_state.data_ptr()
     call("vfa_mha_varlen_bwd" if varlen else "vfa_mha_bwd", P)
     return dq, dk, dv, sd

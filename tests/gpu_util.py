@@ -14,7 +14,7 @@ def to_dev(bits, dtype):
 
 
 def f32(t):
-    return t.float().cpu().numpy()
+    return t.detach().float().cpu().numpy()
 
 
 def as_f32(bits, dtype):

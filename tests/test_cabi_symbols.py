@@ -53,9 +53,13 @@ def test_argument_checks_without_gpu():
     rc = cabi.lib().vfa_mha_fwd(ctypes.byref(P))
     assert rc == -1 and b"must divide number of heads in query" in cabi.lib().vfa_last_error()
     P.h_k = 3
-    P.p_dropout = 0.5
+    P.p_dropout = 1.0  # flash_api.cpp:114
     rc = cabi.lib().vfa_mha_fwd(ctypes.byref(P))
-    assert rc == -1 and b"does not support dropout" in cabi.lib().vfa_last_error()
+    assert rc == -1 and b"p_dropout must be in [0, 1)" in cabi.lib().vfa_last_error()
+    P.p_dropout = 0.0
+    P.s_dmask = 8  # flash_api.cpp:352
+    rc = cabi.lib().vfa_mha_fwd(ctypes.byref(P))
+    assert rc == -1 and b"return_softmax is only supported when p_dropout > 0.0" in cabi.lib().vfa_last_error()
 
 
 def test_python_package_imports_and_signatures():

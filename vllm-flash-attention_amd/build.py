@@ -22,7 +22,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
-HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip"]
+HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
+               "bwd_drop.hip"]
+# the dropout translation units are one-line includes of the kernel sources
+EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
 
@@ -46,7 +49,7 @@ def build_hip(force=False):
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _newer(o, [s] + hdrs):
+        if force or _newer(o, [s] + hdrs + [os.path.join(CSRC, e) for e in EXTRA_DEPS.get(src, [])]):
             jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:

@@ -17,6 +17,8 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream);
 hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream);
 hipError_t run_append_kv(const KParams &p, hipStream_t stream);
 hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
+hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream);
+hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
 }  // namespace vfa
 
 using vfa::KParams;
@@ -80,7 +82,8 @@ static int common_checks(const vfa_params *p) {
     VFA_CHECK(p->d % 8 == 0, "head dimension must be a multiple of 8 (pad before calling)");
     VFA_CHECK(p->h_k > 0 && p->h % p->h_k == 0,
               "Number of heads in key/value must divide number of heads in query");
-    VFA_CHECK(p->p_dropout == 0.f, "This flash attention build does not support dropout.");
+    VFA_CHECK(p->p_dropout >= 0.f && p->p_dropout < 1.f, "p_dropout must be in [0, 1)");  // flash_api.cpp:114
+    VFA_CHECK(!p->s_dmask || p->p_dropout > 0.f, "return_softmax is only supported when p_dropout > 0.0");
     return VFA_OK;
 }
 
@@ -121,6 +124,13 @@ static void fill_common(const vfa_params *p, KParams &k, int seqlen_q_for_fold, 
     k.wl = wl; k.wr = wr;
     k.is_local = (wl >= 0 || wr >= 0) && !k.is_causal;
     k.num_splits = 1;
+    // flash_api.cpp:105-113: keep probability, its 8-bit threshold (rounded down: the test is <=)
+    k.p_keep = 1.f - p->p_dropout;
+    k.drop_keep_u8 = (int)(uint8_t)std::floor(k.p_keep * 255.0);
+    k.rp_dropout = 1.f / k.p_keep;
+    k.scale_rp = p->p_dropout > 0.f ? k.rp_dropout * k.scale : k.scale;
+    k.philox_seed = p->philox_seed; k.philox_offset = p->philox_offset;
+    k.rng_state = (unsigned long long *)p->rng_state;
 }
 
 extern "C" int vfa_num_splits_heuristic(int batch_nheads_mblocks, int num_sms, int num_n_blocks,
@@ -165,6 +175,21 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
         e = vfa::run_append_kv(k, stream);
         if (e != hipSuccess) return hip_fail(e, "append_kv launch");
         // the cache now holds the new rows; the attention kernels read it as a longer cache
+    }
+    if (p->p_dropout > 0.f) {
+        // flash_api.cpp:206 (no split with dropout), :296 / :919 (no decode fold, no kv-cache path)
+        VFA_CHECK(p->num_splits <= 1 && !force_split && !k.knew,
+                  "dropout is not supported with split-KV, paged KV or KV-cache append");
+        if (p->s_dmask) {
+            VFA_CHECK(p->seqlen_q_rounded % 128 == 0 && p->seqlen_q_rounded >= k.seqlen_q &&
+                      p->seqlen_k_rounded % 128 == 0 && p->seqlen_k_rounded >= k.seqlen_k,
+                      "s_dmask needs seqlen_q_rounded / seqlen_k_rounded (multiples of 128)");
+            k.s_dmask = p->s_dmask;
+            k.sq_rounded_p = p->seqlen_q_rounded; k.sk_rounded_p = p->seqlen_k_rounded;
+        }
+        e = vfa::run_fwd_prefill_dropout(k, stream);
+        if (e != hipSuccess) return hip_fail(e, "prefill (dropout) launch");
+        return VFA_OK;
     }
     if (p->num_splits > 1) {
         VFA_CHECK(p->num_splits <= 128, "num_splits > 128 not supported");
@@ -214,7 +239,7 @@ extern "C" int vfa_mha_varlen_fwd(const vfa_params *p) {
     // flash_api.cpp:493-494,515-516: the varlen entry folds with the MAX lengths
     fill_common(p, k, p->seqlen_q, p->seqlen_k);
     k.k_cumulative = 1;
-    return launch_fwd(p, k, false);
+    return launch_fwd(p, k, p->p_dropout > 0.f && p->block_table);
 }
 
 extern "C" int vfa_mha_fwd_kvcache(const vfa_params *p) {
@@ -223,6 +248,7 @@ extern "C" int vfa_mha_fwd_kvcache(const vfa_params *p) {
     if (rc) return rc;
     if ((rc = check_arch())) return rc;
     VFA_CHECK(!p->cu_seqlens_q, "fwd_kvcache takes a dense query batch");
+    VFA_CHECK(p->p_dropout == 0.f, "fwd_kvcache has no dropout");
     VFA_CHECK(!(p->block_table && p->cache_batch_idx), "Paged KVcache does not support cache_batch_idx");
     VFA_CHECK(!p->block_table || p->page_block_size % 16 == 0,
               "Paged KV cache block size must be divisible by 16");
@@ -276,7 +302,10 @@ static int bwd_common(const vfa_params *p, bool varlen) {
     k.dq_accum = p->dq_accum;
     k.deterministic = p->deterministic;
     k.seqlen_q_rounded = (p->seqlen_q + 127) / 128 * 128;
-    hipError_t e = vfa::run_bwd(k, (hipStream_t)p->stream, (hipEvent_t *)p->stage_events);
+    k.rng_read = p->rng_state != nullptr;
+    hipError_t e = p->p_dropout > 0.f
+                       ? vfa::run_bwd_dropout(k, (hipStream_t)p->stream, (hipEvent_t *)p->stage_events)
+                       : vfa::run_bwd(k, (hipStream_t)p->stream, (hipEvent_t *)p->stage_events);
     if (e != hipSuccess) return hip_fail(e, "backward launch");
     return VFA_OK;
 }

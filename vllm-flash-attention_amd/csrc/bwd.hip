@@ -6,6 +6,10 @@
 // Math (standard FA-2): with S = Q K^T (+ALiBi, masks) and the forward's LSE,
 //   P = exp2(S*scale_log2 - LSE*log2e),  dV = P16^T dO,  dP = dO V^T,  delta = rowsum(dO * O),
 //   dS = P * (dP - delta),  dK = scale * dS16^T Q,  dQ = scale * dS16 K.
+// With dropout (template parameter DROP; keep mask M from the forward's Philox stream, keep
+// probability pk; the upstream FlashAttention-2 formulation behind the rp_dropout /
+// scale_softmax_rp_dropout fields, flash.h:109-117): dV = (P16 * M)^T dO / pk, delta is scaled by
+// pk, dS = P * (M * dP - pk delta), and dQ, dK carry scale / pk.
 //
 // Three kernels, no atomics (dq, dk, dv are bitwise reproducible):
 //   bwd_preprocess : delta (the softmax_d output), one 16-lane group per query row
@@ -27,6 +31,9 @@
 
 namespace vfa {
 
+#if defined(VFA_STAMP) && defined(VFA_DROPOUT_TU)
+#undef VFA_STAMP
+#endif
 #ifdef VFA_STAMP
 // Diagnostic build only: per-phase shader-clock sums of the dK/dV step loop.
 __device__ unsigned long long g_stamps_dkdv[512 * 8 * 8];
@@ -75,7 +82,7 @@ bwd_preprocess_kernel(const KParams p) {
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
-    if (lane16 == 0) p.dsoftmax_sum[(int64_t)bh * p.seqlen_q_rounded + sqi] = acc;
+    if (lane16 == 0) p.dsoftmax_sum[(int64_t)bh * p.seqlen_q_rounded + sqi] = acc * p.p_keep;  // p_keep = 1 without dropout
 }
 
 // dK/dV kernel geometry.  NW waves x 32 keys per workgroup.  NW = 8 (two waves per SIMD, <= 256
@@ -111,7 +118,7 @@ struct BwdCfg {
     static constexpr int QCH = (QM * CPR + NT - 1) / NT;      // chunks per thread per Q (or dO) slice
 };
 
-template <int DP, bool BF16, int NW, bool FAST>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP>
 __global__ void __launch_bounds__(NW * 64, 1)
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
@@ -154,6 +161,14 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const int k0 = n_block * KB;
     if (k0 >= sk) return;
     const int kw0 = k0 + 32 * wave;  // first key of this wave
+    // dropout: the forward's Philox state; 1 KiB of LDS per wave behind the kernel's own map
+    unsigned long long ph_seed = 0, ph_off = 0;
+    unsigned *xch = nullptr;
+    if constexpr (DROP) {
+        ph_seed = p.rng_read ? p.rng_state[0] : p.philox_seed;
+        ph_off = p.rng_read ? p.rng_state[1] : p.philox_offset;
+        xch = (unsigned *)(smem + Cfg::LDS_BYTES) + 256 * wave;
+    }
 
     // query-slice range that can see this key block
     int m_min = 0, m_max = (sq + BW_QM - 1) / BW_QM;
@@ -429,13 +444,26 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         STAMP(3);
         // 16-bit B operands: k-step ks2 (16 query rows) = regs 8 ks2 .. 8 ks2 + 7
         i32x4 pf[2], dsf[2];
+        unsigned keep = 0xffffu;
+        if constexpr (DROP)
+            keep = keep_bits_klane(ph_seed, ph_off + (unsigned long long)((bidb * p.h + bidh) * 32), q0 >> 4,
+                                   kw0 >> 5, lane, p.drop_keep_u8, xch);
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ks2++)
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const int j = 8 * ks2 + 2 * w;
-                pf[ks2][w] = pack2<BF16>(s[j], s[j + 1]);
-                dsf[ks2][w] = pack2<BF16>(s[j] * dp[j], s[j + 1] * dp[j + 1]);
+                if constexpr (DROP) {
+                    // dropped entries: no contribution to dV, and dP' = -delta (dP masked to 0)
+                    const bool k0 = (keep >> j) & 1u, k1 = (keep >> (j + 1)) & 1u;
+                    const float nd0 = -dl_s[8 * (j >> 2) + 4 * hh + (j & 3)];
+                    const float nd1 = -dl_s[8 * (j >> 2) + 4 * hh + (j & 3) + 1];
+                    pf[ks2][w] = pack2<BF16>(k0 ? s[j] : 0.f, k1 ? s[j + 1] : 0.f);
+                    dsf[ks2][w] = pack2<BF16>(s[j] * (k0 ? dp[j] : nd0), s[j + 1] * (k1 ? dp[j + 1] : nd1));
+                } else {
+                    pf[ks2][w] = pack2<BF16>(s[j], s[j + 1]);
+                    dsf[ks2][w] = pack2<BF16>(s[j] * dp[j], s[j + 1] * dp[j + 1]);
+                }
             }
 
         // ---- dV^T += dO^T P,  dK^T += Q^T dS  (A operands by transposed reads of the slice) ----
@@ -501,11 +529,13 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             for (int g4 = 0; g4 < 4; g4++) {
                 i32x2 w2;
                 if (which == 0) {
-                    w2[0] = pack2<BF16>(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale);
-                    w2[1] = pack2<BF16>(dk[db][4 * g4 + 2] * p.scale, dk[db][4 * g4 + 3] * p.scale);
+                    // scale_rp = scale / keep probability (= scale without dropout)
+                    w2[0] = pack2<BF16>(dk[db][4 * g4] * p.scale_rp, dk[db][4 * g4 + 1] * p.scale_rp);
+                    w2[1] = pack2<BF16>(dk[db][4 * g4 + 2] * p.scale_rp, dk[db][4 * g4 + 3] * p.scale_rp);
                 } else {
-                    w2[0] = pack2<BF16>(dv[db][4 * g4], dv[db][4 * g4 + 1]);
-                    w2[1] = pack2<BF16>(dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
+                    const float rp = DROP ? p.rp_dropout : 1.f;
+                    w2[0] = pack2<BF16>(dv[db][4 * g4] * rp, dv[db][4 * g4 + 1] * rp);
+                    w2[1] = pack2<BF16>(dv[db][4 * g4 + 2] * rp, dv[db][4 * g4 + 3] * rp);
                 }
                 *(i32x2 *)(ob + r * Cfg::OUT_ROWB + (32 * db + 8 * g4 + 4 * hh) * 2) = w2;
             }
@@ -531,24 +561,27 @@ static bool bwd_fits_buffer(const KParams &p) {
     return rq * p.q_rs * 2 < lim && rq * p.do_rs * 2 < lim && rk * p.k_rs * 2 < lim && rk * p.v_rs * 2 < lim;
 }
 
-template <int DP, bool BF16, int NW, bool FAST>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
 static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
     using Cfg = BwdCfg<DP, NW>;
+    constexpr int LDS = Cfg::LDS_BYTES + (DROP ? NW * 1024 : 0);  // + the Philox exchange space
     const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST>;
-    if (Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP>;
+    if (LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_kblocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), LDS, stream, p, n_kblocks);
     return hipGetLastError();
 }
 
-template <int DP, bool BF16, int NW>
+template <int DP, bool BF16, int NW, bool DROP>
 static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
-    if constexpr (DP == 256) {  // no registers to spare for the buffer-load offsets
+    if constexpr (DROP) {  // one variant (generic loads) per geometry
+        return launch_dkdv_impl<DP, BF16, NW, false, true>(p, stream);
+    } else if constexpr (DP == 256) {  // no registers to spare for the buffer-load offsets
         return launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
     } else {
         return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
@@ -573,7 +606,7 @@ struct DqCfg {
     static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
 };
 
-template <int DP, bool BF16, int NW, bool FAST>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 bwd_dq_kernel(const KParams p, const int n_mblocks) {
     using Cfg = DqCfg<DP, NW>;
@@ -698,6 +731,12 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
             }
         }
         const float lse2 = lse_r * (float)M_LOG2E;
+        unsigned long long ph_seed = 0, ph_off = 0;
+        if constexpr (DROP) {
+            ph_seed = p.rng_read ? p.rng_state[0] : p.philox_seed;
+            ph_off = (p.rng_read ? p.rng_state[1] : p.philox_offset) +
+                     (unsigned long long)((bidb * p.h + bidh) * 32);  // dropout.h:21
+        }
         float alibi = 0.f;
         const bool has_alibi = p.alibi_slopes != nullptr;
         if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
@@ -751,10 +790,14 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
                     }
                 }
                 i32x4 dsf[2];
+                unsigned keep = 0xffffu;
+                if constexpr (DROP)
+                    keep = keep_bits_qlane(ph_seed, ph_off, q0w >> 4, (c0 >> 5) + kb2, r, hh, p.drop_keep_u8);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j], c2, -lse2));
-                    dp[j] = pe * dp[j];
+                    if constexpr (DROP) dp[j] = pe * (((keep >> j) & 1u) ? dp[j] : -dl_r);  // dP masked to 0
+                    else dp[j] = pe * dp[j];
                 }
 #pragma unroll
                 for (int ks2 = 0; ks2 < 2; ks2++)
@@ -789,8 +832,8 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; g4++) {
             i32x2 w;
-            w[0] = pack2<BF16>(dq[db][4 * g4 + 0] * p.scale, dq[db][4 * g4 + 1] * p.scale);
-            w[1] = pack2<BF16>(dq[db][4 * g4 + 2] * p.scale, dq[db][4 * g4 + 3] * p.scale);
+            w[0] = pack2<BF16>(dq[db][4 * g4 + 0] * p.scale_rp, dq[db][4 * g4 + 1] * p.scale_rp);
+            w[1] = pack2<BF16>(dq[db][4 * g4 + 2] * p.scale_rp, dq[db][4 * g4 + 3] * p.scale_rp);
             *(i32x2 *)(ob + r * Cfg::O_ROWB + (32 * db + 8 * g4 + 4 * hh) * 2) = w;
         }
     __syncthreads();
@@ -804,13 +847,13 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW, bool FAST>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
 static hipError_t launch_dq_impl(const KParams &p, hipStream_t stream) {
     using Cfg = DqCfg<DP, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dq_kernel<DP, BF16, NW, FAST>;
+    auto kern = bwd_dq_kernel<DP, BF16, NW, FAST, DROP>;
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -825,7 +868,7 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
                               : launch_dq_impl<DP, BF16, NW, false>(p, stream);
 }
 
-template <int DP, bool BF16>
+template <int DP, bool BF16, bool DROP>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
     hipError_t e;
     if (ev) (void)hipEventRecord(ev[0], stream);
@@ -834,8 +877,8 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         hipLaunchKernelGGL(bwd_preprocess_kernel<BF16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p);
     }
     if (ev) (void)hipEventRecord(ev[1], stream);
-    if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4>(p, stream);
-    else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8>(p, stream) : launch_dkdv<DP, BF16, 4>(p, stream);
+    if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
+    else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[2], stream);
     {
@@ -844,7 +887,8 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         // (d = 64) by 3..25 %, and without a mask below seqlen 2048; 8 waves win by 3..7 % beyond.
         const bool masked = p.is_causal || p.is_local;
         const bool big = masked ? p.seqlen_q >= (DP == 64 ? 8192 : 4096) : p.seqlen_q >= 2048;
-        if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
+        if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
+        else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;
     }
@@ -852,16 +896,25 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     return hipGetLastError();
 }
 
+#ifndef VFA_DROPOUT_TU
 hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
     const bool bf = p.is_bf16;
-    if (p.d <= 64) return bf ? launch_bwd<64, true>(p, stream, ev) : launch_bwd<64, false>(p, stream, ev);
-    if (p.d <= 128) return bf ? launch_bwd<128, true>(p, stream, ev) : launch_bwd<128, false>(p, stream, ev);
-    return bf ? launch_bwd<256, true>(p, stream, ev) : launch_bwd<256, false>(p, stream, ev);
+    if (p.d <= 64) return bf ? launch_bwd<64, true, false>(p, stream, ev) : launch_bwd<64, false, false>(p, stream, ev);
+    if (p.d <= 128) return bf ? launch_bwd<128, true, false>(p, stream, ev) : launch_bwd<128, false, false>(p, stream, ev);
+    return bf ? launch_bwd<256, true, false>(p, stream, ev) : launch_bwd<256, false, false>(p, stream, ev);
 }
+#else   // the dropout variants are compiled as a translation unit of their own (bwd_drop.hip)
+hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
+    const bool bf = p.is_bf16;
+    if (p.d <= 64) return bf ? launch_bwd<64, true, true>(p, stream, ev) : launch_bwd<64, false, true>(p, stream, ev);
+    if (p.d <= 128) return bf ? launch_bwd<128, true, true>(p, stream, ev) : launch_bwd<128, false, true>(p, stream, ev);
+    return bf ? launch_bwd<256, true, true>(p, stream, ev) : launch_bwd<256, false, true>(p, stream, ev);
+}
+#endif
 
 }  // namespace vfa
 
-#ifdef VFA_STAMP
+#if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU)
 extern "C" int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_dkdv), n * sizeof(unsigned long long));
 }

@@ -19,6 +19,9 @@
 
 namespace vfa {
 
+#if defined(VFA_STAMP) && defined(VFA_DROPOUT_TU)
+#undef VFA_STAMP
+#endif
 #ifdef VFA_STAMP
 // Diagnostic build only: per-phase shader-clock sums of the tile loop (never in the product build).
 __device__ unsigned long long g_stamps[4096 * 8];
@@ -82,7 +85,11 @@ __device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks,
 // tiles are fetched with buffer loads whose descriptor ends at the last valid key row: the key
 // tail and the head-dim padding read as zeros without any predication or 64-bit address
 // arithmetic in the tile loop.
-template <int DP, bool BF16, int NW, bool FAST>
+//
+// DROP: dropout on P (flash_fwd_kernel.h:324-337, dropout.h) with the reference's Philox pattern,
+// and the optional Return_softmax output.  The reference point of the exponentials then follows
+// the running maximum exactly (tile by tile, like the reference), because S_dmask exposes it.
+template <int DP, bool BF16, int NW, bool FAST, bool DROP>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
@@ -102,7 +109,14 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
+    if constexpr (DROP) {  // flash_fwd_kernel.h:51-54
+        if (blockIdx.x == 0 && tid == 0 && p.rng_state) {
+            p.rng_state[0] = p.philox_seed;
+            p.rng_state[1] = p.philox_offset;
+        }
+    }
     if (m_block * BM >= sq) return;
+    const unsigned long long drop_off = p.philox_offset + (unsigned long long)((bidb * p.h + bidh) * 32);  // dropout.h:21
 
     // ---- key tile range: flash_fwd_kernel.h:59-67 ----
     int n_min = !p.is_local ? 0 : max(0, (m_block * BM + sk - sq - p.wl) / BN);
@@ -318,7 +332,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks]);
             s[0] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[0]);
         }
-        constexpr bool SPEC = DP >= 128;  // measured: +1..2 % at d = 128, -2.5 % at d = 64
+        constexpr bool SPEC = DP >= 128 && !DROP;  // measured: +1..2 % at d = 128, -2.5 % at d = 64
         const float mc_old = (m_run == -INFINITY ? 0.f : m_run) * c2;
         float mx = -INFINITY;
         if constexpr (!SPEC) {
@@ -392,7 +406,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         // (for every row of the wave at once) only when some row's maximum outgrew it by more
         // than 2^RESCALE_LOG2, so P stays below that bound and the rescale of O becomes rare.
         // Any reference point gives the same O and LSE up to rounding.
-        constexpr float RESCALE_LOG2 = 4.f;
+        constexpr float RESCALE_LOG2 = DROP ? 0.f : 4.f;
         const bool upd = __any((mx - m_run) * c2 > RESCALE_LOG2);
         const float m_new = upd ? fmaxf(m_run, mx) : m_run;
         const float m_cur = (m_new == -INFINITY) ? 0.f : m_new;
@@ -417,13 +431,37 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             exp_step(0, mc);
         }
 
+        if constexpr (DROP) {
+            exp_step(1, mc); exp_step(2, mc); exp_step(3, mc);
+            unsigned short *sd = nullptr;
+            if (p.s_dmask)
+                sd = (unsigned short *)p.s_dmask +
+                     (((int64_t)bidb * p.h + bidh) * p.sq_rounded_p + q0w + r) * p.sk_rounded_p + c0 + 4 * hh;
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; kb2++) {
+                const unsigned keep = keep_bits_qlane(p.philox_seed, drop_off, q0w >> 4, (c0 >> 5) + kb2,
+                                                      r, hh, p.drop_keep_u8);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int ks = 2 * kb2 + e, j = 8 * e + 2 * w;
+                        const unsigned k0 = (keep >> j) & 1u, k1 = (keep >> (j + 1)) & 1u;
+                        // sign bit = dropped (dropout.h:31-33); registers j, j+1 are adjacent keys
+                        if (sd)
+                            *(unsigned *)(sd + 32 * kb2 + (j & 3) + 8 * (j >> 2)) =
+                                (unsigned)pf[ks][w] ^ ((k0 ^ 1u) << 15) ^ ((k1 ^ 1u) << 31);
+                        pf[ks][w] &= (int)((k0 ? 0xffffu : 0u) | (k1 ? 0xffff0000u : 0u));
+                    }
+            }
+        }
         STAMP(2);
         // ---- O^T += V^T P^T.  P fragment of k-step ks (16 keys) = regs 8(ks&1).. of s[ks>>1];
         // element j of lane half hh is key 16 ks + 8 (j>>2) + 4 hh + (j&3). ----
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             if constexpr (SPEC) { if (ks < 2) exp_step(ks + 2, mc); }  // next to the MFMAs of k-step ks
-            else { if (ks < 3) exp_step(ks + 1, mc); }
+            else if constexpr (!DROP) { if (ks < 3) exp_step(ks + 1, mc); }
 #pragma unroll
             for (int db = 0; db < NDB; db++) {
                 const s16x4 v0 = lds_read_tr16(vb + v_rd[db][0] + 16 * ks * ROWB);
@@ -462,7 +500,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     // ---- epilogue: normalise, LSE (softmax.h:168-185), store O through LDS as whole rows ----
     const float l_tot = half_swap_sum(l_run);
     const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
-    const float inv = bad ? 1.f : 1.f / l_tot;
+    const float inv = (bad ? 1.f : 1.f / l_tot) * (DROP ? p.rp_dropout : 1.f);  // softmax.h:181
     const float lse = bad ? INFINITY : m_run * p.scale + __logf(l_tot);
     if (hh == 0 && q0w + r < sq) lse_g[q0w + r] = lse;
 
@@ -489,13 +527,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW, bool FAST>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
 static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_prefill_kernel<DP, BF16, NW, FAST>;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW, FAST, DROP>;
     if (Cfg::LDS_BYTES > 64 * 1024) {  // per device and cheap: set on every launch
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -506,6 +544,7 @@ static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifndef VFA_DROPOUT_TU
 // Contiguous K/V whose per-(batch, head) extent fits a 32-bit buffer offset take the buffer-load path.
 static bool kv_fits_buffer(const KParams &p) {
     if (p.block_table) return false;
@@ -541,9 +580,24 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     }
 }
 
+#else   // VFA_DROPOUT_TU: the dropout variants are compiled as a translation unit of their own
+// Dropout is a training feature: one geometry (4 waves, generic loads) per head dim.
+hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream) {
+    const bool bf = p.is_bf16;
+    if (p.d <= 64)
+        return bf ? launch_prefill_impl<64, true, 4, false, true>(p, stream)
+                  : launch_prefill_impl<64, false, 4, false, true>(p, stream);
+    if (p.d <= 128)
+        return bf ? launch_prefill_impl<128, true, 4, false, true>(p, stream)
+                  : launch_prefill_impl<128, false, 4, false, true>(p, stream);
+    return bf ? launch_prefill_impl<256, true, 4, false, true>(p, stream)
+              : launch_prefill_impl<256, false, 4, false, true>(p, stream);
+}
+#endif  // VFA_DROPOUT_TU
+
 }  // namespace vfa
 
-#ifdef VFA_STAMP
+#if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU)
 extern "C" int vfa_debug_read_stamps(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps), n * sizeof(unsigned long long));
 }

@@ -5,6 +5,7 @@
 // vllm_flash_attn/flash_attn_interface.py:135-154 and :183-207 (the fork exports no backward).
 #include <torch/python.h>
 #include <torch/nn/functional.h>
+#include <ATen/hip/HIPGeneratorImpl.h>
 #include <ATen/hip/HIPContext.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -87,12 +88,43 @@ void plan_splits(vfa_params &P, SplitScratch &S, int num_splits, int64_t b, int6
     }
 }
 
+int64_t round128(int64_t x) { return (x + 127) / 128 * 128; }
+
+// Dropout set-up shared by fwd / varlen_fwd (flash_api.cpp:349-354,379-394): the optional
+// Return_softmax tensor and the Philox state.  The generator's offset advances by b * h * 32, the
+// number of draws the kernels index per (batch, head) (dropout.h:21).
+Tensor plan_dropout(vfa_params &P, double p_dropout, bool return_softmax, int64_t b, int64_t h,
+                    int64_t sq, int64_t sk, const at::TensorOptions &opts, Tensor &rng_state,
+                    std::optional<at::Generator> &gen_) {
+    TORCH_CHECK(p_dropout >= 0.0 && p_dropout < 1.0, "p_dropout must be in [0, 1)");
+    Tensor p;
+    if (return_softmax) {
+        TORCH_CHECK(p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
+        // zero-filled (the reference leaves tiles its kernel never visits uninitialised)
+        p = torch::zeros({b, h, round128(sq), round128(sk)}, opts);
+        P.s_dmask = p.data_ptr();
+        P.seqlen_q_rounded = (int)round128(sq);
+        P.seqlen_k_rounded = (int)round128(sk);
+    }
+    P.p_dropout = (float)p_dropout;
+    P.rng_state = (uint64_t *)rng_state.data_ptr<int64_t>();
+    if (p_dropout > 0.0) {
+        auto gen = at::get_generator_or_default<at::CUDAGeneratorImpl>(
+            gen_, at::cuda::detail::getDefaultCUDAGenerator());
+        std::lock_guard<std::mutex> lock(gen->mutex_);
+        const auto seed_offset = gen->philox_engine_inputs((uint64_t)(b * h * 32));
+        P.philox_seed = seed_offset.first;
+        P.philox_offset = seed_offset.second;
+    }
+    return p;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fwd  (flash_api.cpp:240-420)
 std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &out_,
                         OptTensor &alibi_slopes_, const double p_dropout, const double softmax_scale,
                         bool is_causal, int64_t window_size_left, int64_t window_size_right,
-                        const bool return_softmax, std::optional<at::Generator> /*gen_*/) {
+                        const bool return_softmax, std::optional<at::Generator> gen_) {
     const int dt = dtype_code(q);
     TORCH_CHECK(k.scalar_type() == q.scalar_type(), "query and key must have the same dtype");
     TORCH_CHECK(v.scalar_type() == q.scalar_type(), "query and value must have the same dtype");
@@ -107,8 +139,6 @@ std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &
     TORCH_CHECK(b > 0, "batch size must be postive");
     TORCH_CHECK(d_og <= 256, "FlashAttention forward only supports head dimension at most 256");
     TORCH_CHECK(hk > 0 && h % hk == 0, "Number of heads in key/value must divide number of heads in query");
-    TORCH_CHECK(p_dropout == 0.0, "This flash attention build does not support dropout.");
-    TORCH_CHECK(!return_softmax, "return_softmax is only supported when p_dropout > 0.0");
 
     // Single-token GQA decode: fold the query heads of a KV group into the row dimension
     // (flash_api.cpp:296-304) so one K/V stream serves the whole group.
@@ -117,7 +147,7 @@ std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &
     if (wr >= sk) wr = -1;
     const bool causal_eff = is_causal && !(sq == 1 && !alibi_slopes_.has_value());
     const bool fold = sq == 1 && h > hk && wl < 0 && wr < 0 && !causal_eff && d_og % 8 == 0 &&
-                      !alibi_slopes_.has_value();
+                      !alibi_slopes_.has_value() && p_dropout == 0.0;
     const int64_t g = h / hk;
     if (fold) {
         q = q.reshape({b, hk, g, d_og}).transpose(1, 2);
@@ -147,9 +177,9 @@ std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &
     auto opts = q.options();
     Tensor lse = torch::empty({b, h, sq}, opts.dtype(at::kFloat));
     Tensor rng_state = torch::empty({2}, opts.dtype(at::kLong));
-    Tensor p_unused;
 
     vfa_params P{};
+    Tensor p_unused = plan_dropout(P, p_dropout, return_softmax, b, h, sq, sk, opts, rng_state, gen_);
     P.dtype = dt;
     set_qkvo(P, qp, kp, vp, out, true);
     P.softmax_lse = lse.data_ptr<float>();
@@ -161,7 +191,7 @@ std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &
     set_alibi(P, alibi_slopes_, b, h);
     SplitScratch scratch;
     if (sk > 0) {
-        plan_splits(P, scratch, 0, b, h, d, sk, sq, opts);
+        if (p_dropout == 0.0) plan_splits(P, scratch, 0, b, h, d, sk, sq, opts);  // flash_api.cpp:206
         P.stream = current_stream();
         run(vfa_mha_fwd(&P));
     } else {  // flash_api.cpp:401-405
@@ -191,7 +221,7 @@ std::vector<Tensor> varlen_fwd(Tensor &q, const Tensor &k, const Tensor &v, OptT
                                int64_t max_seqlen_q, const int64_t max_seqlen_k, const double p_dropout,
                                const double softmax_scale, const bool zero_tensors, bool is_causal,
                                int64_t window_size_left, int64_t window_size_right,
-                               const bool return_softmax, std::optional<at::Generator> /*gen_*/) {
+                               const bool return_softmax, std::optional<at::Generator> gen_) {
     const int dt = dtype_code(q);
     TORCH_CHECK(k.scalar_type() == q.scalar_type(), "query and key must have the same dtype");
     TORCH_CHECK(v.scalar_type() == q.scalar_type(), "query and value must have the same dtype");
@@ -221,15 +251,14 @@ std::vector<Tensor> varlen_fwd(Tensor &q, const Tensor &k, const Tensor &v, OptT
     const int64_t num_blocks = paged ? k.size(0) : 0;
     const int64_t page = paged ? k.size(1) : 1;
     TORCH_CHECK(!paged || page % 16 == 0, "Paged KV cache block size must be divisible by 16");
-    TORCH_CHECK(p_dropout == 0.0, "This flash attention build does not support dropout.");
-    TORCH_CHECK(!return_softmax, "return_softmax is only supported when p_dropout > 0.0");
+    TORCH_CHECK(!(paged && p_dropout > 0.0), "dropout is not supported with a paged KV cache");
 
     int64_t wl = window_size_left, wr = window_size_right;
     if (wl >= max_seqlen_k) wl = -1;
     if (wr >= max_seqlen_k) wr = -1;
     const bool causal_eff = is_causal && !(max_seqlen_q == 1 && !alibi_slopes_.has_value());
     const bool fold = max_seqlen_q == 1 && h > hk && wl < 0 && wr < 0 && !causal_eff &&
-                      d_og % 8 == 0 && !alibi_slopes_.has_value();
+                      d_og % 8 == 0 && !alibi_slopes_.has_value() && p_dropout == 0.0;
     const int64_t g = h / std::max<int64_t>(hk, 1);
     bool dense_q = false;
     if (fold) {  // flash_api.cpp:500-507: every sequence has exactly one query token
@@ -281,13 +310,14 @@ std::vector<Tensor> varlen_fwd(Tensor &q, const Tensor &k, const Tensor &v, OptT
     auto opts = q.options();
     Tensor lse = torch::empty({b, h, max_seqlen_q}, opts.dtype(at::kFloat));
     Tensor rng_state = torch::empty({2}, opts.dtype(at::kLong));
-    Tensor p_unused;
     if (zero_tensors) {
         out.zero_();
         lse.fill_(-std::numeric_limits<float>::infinity());
     }
 
     vfa_params P{};
+    Tensor p_unused = plan_dropout(P, p_dropout, return_softmax, b, h, max_seqlen_q, max_seqlen_k, opts,
+                                   rng_state, gen_);
     P.dtype = dt;
     set_qkvo(P, qp, kp, vp, out, false);
     P.softmax_lse = lse.data_ptr<float>();
@@ -526,7 +556,8 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
                              OptTensor &alibi_slopes_, int64_t max_seqlen_q, int64_t max_seqlen_k,
                              const double p_dropout, const double softmax_scale, const bool zero_tensors,
                              const bool is_causal, int64_t window_size_left, int64_t window_size_right,
-                             const bool deterministic) {
+                             const bool deterministic, std::optional<at::Generator> gen_,
+                             OptTensor &rng_state_) {
     const bool varlen = cu_seqlens_q != nullptr;
     const int dt = dtype_code(q);
     for (const Tensor *t : {&k, &v, &out, &dout})
@@ -534,7 +565,7 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
     for (const Tensor *t : {&q, &k, &v, &out, &dout, &softmax_lse}) expect_gpu(*t, "input");
     for (const Tensor *t : {&q, &k, &v, &out, &dout})
         TORCH_CHECK(t->stride(-1) == 1, "Input tensor must have contiguous last dimension");
-    TORCH_CHECK(p_dropout == 0.0, "This flash attention build does not support dropout.");
+    TORCH_CHECK(p_dropout >= 0.0 && p_dropout < 1.0, "p_dropout must be in [0, 1)");
     TORCH_CHECK(softmax_lse.scalar_type() == at::kFloat, "softmax_lse must be fp32");
 
     int64_t b, sq, sk, h, hk, d, total_q = 0, total_k = 0;
@@ -611,6 +642,24 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
     if (h != hk) { P.dk_accum = dk_accum.data_ptr<float>(); P.dv_accum = dv_accum.data_ptr<float>(); }
     P.deterministic = deterministic;
     P.stream = current_stream();
+    // The forward's Philox state: the rng_state tensor it returned (read on the device), else a
+    // fresh draw from the generator like the upstream backward does when none is passed.
+    P.p_dropout = (float)p_dropout;
+    if (p_dropout > 0.0) {
+        if (rng_state_.has_value()) {
+            const Tensor &rs = rng_state_.value();
+            TORCH_CHECK(rs.is_cuda() && rs.scalar_type() == at::kLong && rs.numel() == 2 && rs.is_contiguous(),
+                        "rng_state must be a CUDA int64 tensor with 2 elements");
+            P.rng_state = (uint64_t *)rs.data_ptr<int64_t>();
+        } else {
+            auto gen = at::get_generator_or_default<at::CUDAGeneratorImpl>(
+                gen_, at::cuda::detail::getDefaultCUDAGenerator());
+            std::lock_guard<std::mutex> lock(gen->mutex_);
+            const auto seed_offset = gen->philox_engine_inputs((uint64_t)(b * h * 32));
+            P.philox_seed = seed_offset.first;
+            P.philox_offset = seed_offset.second;
+        }
+    }
     if (sk > 0 && sq > 0) {
         run(varlen ? vfa_mha_varlen_bwd(&P) : vfa_mha_bwd(&P));
     } else {
@@ -624,10 +673,10 @@ std::vector<Tensor> bwd(const Tensor &dout, const Tensor &q, const Tensor &k, co
                         OptTensor &dv_, OptTensor &alibi_slopes_, const double p_dropout,
                         const double softmax_scale, const bool is_causal, int64_t window_size_left,
                         int64_t window_size_right, const bool deterministic,
-                        std::optional<at::Generator> /*gen_*/, OptTensor & /*rng_state*/) {
+                        std::optional<at::Generator> gen_, OptTensor &rng_state) {
     return bwd_impl(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, nullptr, nullptr, alibi_slopes_, 0, 0,
                     p_dropout, softmax_scale, false, is_causal, window_size_left, window_size_right,
-                    deterministic);
+                    deterministic, gen_, rng_state);
 }
 
 std::vector<Tensor> varlen_bwd(const Tensor &dout, const Tensor &q, const Tensor &k, const Tensor &v,
@@ -637,11 +686,11 @@ std::vector<Tensor> varlen_bwd(const Tensor &dout, const Tensor &q, const Tensor
                                const int64_t max_seqlen_k, const double p_dropout,
                                const double softmax_scale, const bool zero_tensors, const bool is_causal,
                                int64_t window_size_left, int64_t window_size_right,
-                               const bool deterministic, std::optional<at::Generator> /*gen_*/,
-                               OptTensor & /*rng_state*/) {
+                               const bool deterministic, std::optional<at::Generator> gen_,
+                               OptTensor &rng_state) {
     return bwd_impl(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, &cu_seqlens_q, &cu_seqlens_k,
                     alibi_slopes_, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale, zero_tensors,
-                    is_causal, window_size_left, window_size_right, deterministic);
+                    is_causal, window_size_left, window_size_right, deterministic, gen_, rng_state);
 }
 
 }  // namespace

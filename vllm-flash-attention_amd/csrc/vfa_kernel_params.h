@@ -48,6 +48,16 @@ struct KParams {
     int seqlen_q_rounded;
     int deterministic;
     int is_bf16;
+    // dropout (dropout.h:12-23, flash_api.cpp:105-113)
+    int drop_keep_u8;            // keep an entry iff its random byte <= this
+    float rp_dropout;            // 1 / (1 - p_dropout)
+    float p_keep;                // 1 - p_dropout
+    float scale_rp;              // scale * rp_dropout
+    unsigned long long philox_seed, philox_offset;
+    unsigned long long *rng_state;   // fwd: written; bwd: read when non-null
+    int rng_read;                // backward: take seed / offset from rng_state
+    void *s_dmask;               // (b, h, sq_rounded_p, sk_rounded_p) 16-bit or null
+    int sq_rounded_p, sk_rounded_p;
 };
 
 // Per-batch lengths and offsets: csrc/flash_attn/src/block_info.h:15-34.
@@ -135,6 +145,87 @@ __device__ __forceinline__ int swz(int row) {
 template <int DP>
 __device__ __forceinline__ int lds_off(int row, int ch) {
     return row * (DP * 2) + ((ch ^ swz<DP>(row)) << 4);
+}
+
+// ---- dropout: Philox-4x32, 7 rounds (csrc/flash_attn/src/philox.cuh:22-49) ----
+struct u32x4s { unsigned x, y, z, w; };
+__device__ __forceinline__ u32x4s philox7(unsigned long long seed, unsigned sub_lo, unsigned sub_hi,
+                                          unsigned long long offset) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned c0 = (unsigned)offset, c1 = (unsigned)(offset >> 32), c2 = sub_lo, c3 = sub_hi;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;  // (the bump after the last round is dead code)
+    }
+    return u32x4s{c0, c1, c2, c3};
+}
+
+// The reference draws one Philox value per lane t (0..31) per 16 x 32 block of the attention
+// matrix: subsequence (row / 16, col / 32), offset + (batch * h + head) * 32 + t, and spends its 16
+// bytes on rows t/4 and t/4 + 8, columns 2 (t%4) + {0, 1} of the four 8-column atoms; byte
+// 4 * atom + 2 * (row >= 8) + (col & 1) decides entry (row, col): kept iff byte <= keep_u8
+// (dropout.h:17-23,39-79; utils.h:215-223).  The two helpers below hand each lane of a 32 x 32
+// score sub-tile the 16 keep bits of its accumulator registers (bit j <-> register j) at the cost
+// of ONE draw per lane: the 64 lanes compute the sub-tile's 64 draws (2 row blocks x 32 lanes)
+// once and exchange them.
+
+// Query on the lane (forward, dQ): lane (r = query row in the wave's 32, hh) holds keys
+// (j&3) + 8 (j>>2) + 4 hh of the 32-key block.  Its entries come from draws t = 4 (r&7) + 2 hh and
+// t + 1 of row block (q0 + r) / 16, half of each; the other halves belong to lane r ^ 8.
+__device__ __forceinline__ unsigned keep_bits_qlane(unsigned long long seed, unsigned long long off_bh,
+                                                    int row_block0, int col_block, int r, int hh,
+                                                    int keep_u8) {
+    const int rh = (r >> 3) & 1;
+    const int t = 4 * (r & 7) + 2 * hh + rh;
+    const u32x4s own = philox7(seed, (unsigned)(row_block0 + (r >> 4)), (unsigned)col_block, off_bh + t);
+    unsigned o[4] = {own.x, own.y, own.z, own.w}, x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = (unsigned)__shfl_xor((int)o[i], 8);
+    unsigned keep = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        // draw t_a (registers with (j>>1)&1 == 0) is `own` on the rh == 0 lane, t_b on the rh == 1 lane
+        const bool mine = (((j >> 1) & 1) == rh);
+        const unsigned dw = mine ? o[j >> 2] : x[j >> 2];
+        const unsigned byte = (dw >> (16 * rh + 8 * (j & 1))) & 0xffu;
+        keep |= (byte <= (unsigned)keep_u8 ? 1u : 0u) << j;
+    }
+    return keep;
+}
+
+// Key on the lane (dK/dV): lane (r = key in the wave's 32, hh) holds query rows
+// (j&3) + 8 (j>>2) + 4 hh of the 32-row sub-block.  Lane L computes draw t = L & 31 of row block
+// row_block0 + (L >> 5); the 8 draws a lane needs are fetched through `xch` (1 KiB of LDS private
+// to the wave).
+__device__ __forceinline__ unsigned keep_bits_klane(unsigned long long seed, unsigned long long off_bh,
+                                                    int row_block0, int col_block, int lane, int keep_u8,
+                                                    unsigned *xch) {
+    const int r = lane & 31, hh = lane >> 5;
+    const u32x4s own = philox7(seed, (unsigned)(row_block0 + hh), (unsigned)col_block, off_bh + r);
+    __builtin_amdgcn_wave_barrier();
+    *(i32x4 *)(xch + 4 * lane) = i32x4{(int)own.x, (int)own.y, (int)own.z, (int)own.w};
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    unsigned keep = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int br = 0; br < 2; br++) {
+            const int src = 4 * (a + 4 * hh) + ((r & 7) >> 1) + 32 * br;
+            const unsigned dw = xch[4 * src + (r >> 3)];
+#pragma unroll
+            for (int rh = 0; rh < 2; rh++) {
+                const int j = a + 4 * rh + 8 * br;
+                const unsigned byte = (dw >> (16 * rh + 8 * (r & 1))) & 0xffu;
+                keep |= (byte <= (unsigned)keep_u8 ? 1u : 0u) << j;
+            }
+        }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    return keep;
 }
 
 }  // namespace vfa

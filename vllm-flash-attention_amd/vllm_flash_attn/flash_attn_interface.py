@@ -11,7 +11,10 @@ Deliberate differences from the reference wrappers:
     one too few since the `out` argument was added, so its backward cannot run), and the packed
     variants take `out` positionally (the reference declares it keyword-only but passes it
     positionally through `.apply`, a TypeError);
-  * the extension exports `bwd` / `varlen_bwd` (the reference fork is forward-only).
+  * the extension exports `bwd` / `varlen_bwd` (the reference fork is forward-only);
+  * dropout_p > 0 and return_attn_probs work (the fork compiles dropout out, setup.py:204): the
+    keep mask is the reference kernel's Philox pattern (dropout.h, philox.cuh) for the state drawn
+    from torch's CUDA generator.
 There is no CPU or eager fallback: without the HIP extension the import fails.
 """
 from typing import Optional, Union
@@ -24,7 +27,8 @@ import vllm_flash_attn_2_cuda as flash_attn_cuda
 
 def _get_block_size_n(device, head_dim, is_dropout, is_causal):
     """Key-tile width of the forward kernel (the reference's helper of the same name, :15-43, kept
-    importable for test code).  The gfx950 prefill kernel always walks 64-key tiles."""
+    importable for test code, which needs it to re-normalise S_dmask).  The gfx950 prefill kernel
+    always walks 64-key tiles."""
     assert head_dim <= 256
     return 64
 
@@ -235,10 +239,12 @@ def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=Fal
                               return_attn_probs=False, *, out=None):
     """Attention on a packed qkv of shape (batch_size, seqlen, 3, nheads, headdim).
 
-    dropout_p must be 0.0 (dropout is not built).  window_size=(left, right) != (-1, -1) selects
-    sliding-window attention; alibi_slopes is (nheads,) or (batch_size, nheads) fp32.
-    Returns out (batch_size, seqlen, nheads, headdim), plus (softmax_lse, None) when
-    return_attn_probs=True.  Same contract as the reference function of this name (:658-713)."""
+    dropout_p drops attention probabilities with the reference kernel's Philox pattern (state from
+    torch's CUDA generator; set it to 0.0 for evaluation).  window_size=(left, right) != (-1, -1)
+    selects sliding-window attention; alibi_slopes is (nheads,) or (batch_size, nheads) fp32.
+    Returns out (batch_size, seqlen, nheads, headdim), plus (softmax_lse, S_dmask) when
+    return_attn_probs=True (S_dmask only with dropout_p > 0, for testing: per 64-key tile
+    exp(score - running max), negative where dropped).  Same contract as the reference function of this name (:658-713)."""
     return FlashAttnQKVPackedFunc.apply(qkv, dropout_p, softmax_scale, causal, window_size,
                                         alibi_slopes, deterministic, return_attn_probs, out)
 
