@@ -307,8 +307,8 @@ def test_error_messages_match_reference():
     with pytest.raises(RuntimeError, match="only support fp16 and bf16"):
         fa.flash_attn_func(q, q, q)
     q = q.half()
-    with pytest.raises(RuntimeError, match="does not support dropout"):
-        fa.flash_attn_func(q, q, q, dropout_p=0.1)
+    with pytest.raises(RuntimeError, match="p_dropout must be in"):  # flash_api.cpp:114
+        fa.flash_attn_func(q, q, q, dropout_p=1.0)
     k = torch.randn(1, 8, 3, 64, device="cuda", dtype=torch.float16)
     with pytest.raises(RuntimeError, match="must divide number of heads in query"):
         fa.flash_attn_func(q, k, k)

@@ -34,6 +34,9 @@ def main():
         acc = torch.empty(1, device="cuda", dtype=torch.float32)
         Pf = bench.build_params(cabi, q, k, v, out, lse, causal, stream)
         Pb = bench.build_params(cabi, q, k, v, out, lse, causal, stream, do, dq, dk, dv, sd, acc)
+        pdrop = float(os.environ.get("VFA_PDROP", "0"))  # dropout variants of the three kernels
+        Pf.p_dropout = Pb.p_dropout = pdrop
+        Pf.philox_seed = Pb.philox_seed = 1234
         n = 10
         for _ in range(3):
             cabi.call("vfa_mha_fwd", Pf); cabi.call("vfa_mha_bwd", Pb)
