@@ -87,9 +87,9 @@ typedef struct vfa_params {
     int64_t dk_batch_stride, dk_row_stride, dk_head_stride;
     int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
     float *dsoftmax_sum;             /* (b, h, seqlen_q rounded up to 128) fp32: rowsum(dO * O) */
-    float *dq_accum;                 /* fp32 scratch shaped like q, contiguous: (b, seqlen_q, h, d) or
-                                        (total_q, h, d); need not be zeroed by the caller */
-    float *dk_accum, *dv_accum;      /* unused (dK/dV of a GQA group are summed in registers) */
+    float *dq_accum;                 /* unused, may be NULL: kept for the field list of flash.h:153-156
+                                        (dQ is accumulated in registers by a query-stationary kernel) */
+    float *dk_accum, *dv_accum;      /* unused, may be NULL (dK/dV of a GQA group are summed in registers) */
     int deterministic;
     void *stream;                    /* hipStream_t */
     /* Optional instrumentation (NULL = off): array of 4 hipEvent_t that vfa_mha_bwd /
@@ -142,8 +142,8 @@ int vfa_num_splits_heuristic(int batch_nheads_mblocks, int num_sms, int num_n_bl
 int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, int max_seqlen_k,
                            int max_seqlen_q, int num_cus);
 
-/* Bytes of fp32 scratch the backward needs for dq_accum / dsoftmax_sum
- * (csrc/flash_attn/src/flash.h:153-156,178-182). */
+/* Elements of the fp32 dq_accum buffer of the reference's parameter block
+ * (csrc/flash_attn/src/flash.h:153-156); this library does not need the buffer. */
 size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_0);
 
 /* sizeof(vfa_params) of the built library, for foreign-function bindings to check their mirror of

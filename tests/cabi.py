@@ -204,8 +204,6 @@ def bwd(dout, q, k, v, out, lse, *, softmax_scale=None, causal=False, window=(-1
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     sq_r = (sq + 127) // 128 * 128
     sd = torch.empty(b, h, sq_r, dtype=torch.float32, device=q.device)
-    dq_acc = torch.zeros(q.shape, dtype=torch.float32, device=q.device)
-    keep = [dq_acc]
     P.q, P.k, P.v, P.out, P.softmax_lse = (t.data_ptr() for t in (q, k, v, out, lse))
     P.dout, P.dq, P.dk, P.dv = (t.data_ptr() for t in (dout, dq, dk, dv))
     for name, t in (("q", q), ("k", k), ("v", v), ("o", out), ("do", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
@@ -219,12 +217,7 @@ def bwd(dout, q, k, v, out, lse, *, softmax_scale=None, causal=False, window=(-1
         P.alibi_slopes_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
     P.softmax_scale = float(softmax_scale if softmax_scale is not None else d ** -0.5)
     P.is_causal, P.window_size_left, P.window_size_right = int(causal), int(window[0]), int(window[1])
-    P.dsoftmax_sum, P.dq_accum = sd.data_ptr(), dq_acc.data_ptr()
-    if h != hk:
-        dka = torch.zeros(k.shape, dtype=torch.float32, device=q.device)
-        dva = torch.zeros(v.shape, dtype=torch.float32, device=q.device)
-        keep += [dka, dva]
-        P.dk_accum, P.dv_accum = dka.data_ptr(), dva.data_ptr()
+    P.dsoftmax_sum = sd.data_ptr()
     P.deterministic = int(deterministic)
     P.stream = _stream()
     P.p_dropout, P.philox_seed, P.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)

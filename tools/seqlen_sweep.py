@@ -12,15 +12,22 @@ import torch.nn.functional as F
 import cabi
 
 
-def med_ms(fn, warm=3, it=10):
+def med_ms(fn, warm=3, it=7, reps=8):
+    """Median over `it` measurements of the mean time of `reps` back-to-back calls: with several
+    calls queued the GPU does not wait for the host between them, so the host-side cost of a call
+    (argument set-up, output allocation) is not billed to kernels that run for tens of microseconds."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(it):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        fn()  # (a call in flight while the timed ones are queued)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / reps)
     return sorted(ts)[len(ts) // 2]
 
 
@@ -52,8 +59,8 @@ def main():
                 rows.append(r)
                 print(json.dumps({k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in r.items()}), flush=True)
     with open(out_path, "w") as f:
-        json.dump({"note": "bf16, 16k tokens per batch, dim 2048; this library through the C ABI (backward timing "
-                           "includes the per-call output allocations of the test helper) vs torch SDPA; MI355X",
+        json.dump({"note": "bf16, 16k tokens per batch, dim 2048; this library through the C ABI vs torch SDPA on the "
+                           "same tensors; each figure is the median of 7 timings of 8 queued calls; MI355X",
                    "rows": rows}, f, indent=1)
 
 

@@ -288,7 +288,7 @@ static int bwd_common(const vfa_params *p, bool varlen) {
     if (rc) return rc;
     if ((rc = check_arch())) return rc;
     VFA_CHECK(p->dout && p->dq && p->dk && p->dv, "null gradient pointer");
-    VFA_CHECK(p->dsoftmax_sum && p->dq_accum, "backward needs dsoftmax_sum / dq_accum scratch");
+    VFA_CHECK(p->dsoftmax_sum, "backward needs the dsoftmax_sum buffer");
     VFA_CHECK(varlen == (p->cu_seqlens_q != nullptr), "cu_seqlens mismatch for this entry point");
     KParams k;
     fill_common(p, k, p->seqlen_q, p->seqlen_k);

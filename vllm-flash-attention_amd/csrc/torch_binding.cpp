@@ -606,13 +606,7 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
     auto opts = q.options();
     const int64_t sq_rounded = (sq + 127) / 128 * 128;
     Tensor softmax_d = torch::empty({b, h, sq_rounded}, opts.dtype(at::kFloat));
-    Tensor dq_accum = varlen ? torch::zeros({total_q, h, d}, opts.dtype(at::kFloat))
-                             : torch::zeros({b, sq, h, d}, opts.dtype(at::kFloat));
-    Tensor dk_accum, dv_accum;
-    if (h != hk) {
-        dk_accum = torch::zeros(k.sizes(), opts.dtype(at::kFloat));
-        dv_accum = torch::zeros(v.sizes(), opts.dtype(at::kFloat));
-    }
+    // (no fp32 dq / dk / dv accumulators: the kernels accumulate in registers, flash.h:153-156)
     if (zero_tensors) { dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_(); }
 
     vfa_params P{};
@@ -638,8 +632,6 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
         P.dk_batch_stride = dk.stride(0); P.dv_batch_stride = dv.stride(0);
     }
     P.dsoftmax_sum = softmax_d.data_ptr<float>();
-    P.dq_accum = dq_accum.data_ptr<float>();
-    if (h != hk) { P.dk_accum = dk_accum.data_ptr<float>(); P.dv_accum = dv_accum.data_ptr<float>(); }
     P.deterministic = deterministic;
     P.stream = current_stream();
     // The forward's Philox state: the rng_state tensor it returned (read on the device), else a
