@@ -144,9 +144,21 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         const int full = (P / 8) * 8 * n_kblocks;
         int pair;
         if (L < full) {
+            // Within an XCD the pairs are taken in groups of G, and within a group the key blocks
+            // go heaviest first ACROSS its pairs (key block 0 of every pair, then key block 1, ...):
+            // under a causal mask key block n sees (n_kblocks - n) / n_kblocks of the rows, and
+            // pair-by-pair order would start the heavy blocks of the next pair only as the light
+            // ones of this pair finish (25 instead of 17 block-units for 4 pairs on 32 CUs).  G is
+            // kept at about two rounds of the XCD's CUs, so the co-resident blocks still come from
+            // few pairs and share their Q / dO slices through L2.
             const int x = L & 7, sl = L >> 3;
-            pair = (sl / n_kblocks) * 8 + x;
-            n_block = sl % n_kblocks;
+            const int ppx = P / 8;
+            const int G = max(1, min(ppx, (64 + n_kblocks - 1) / n_kblocks));
+            const int g = sl / (G * n_kblocks);
+            const int within = sl - g * G * n_kblocks;
+            const int Gl = min(G, ppx - g * G);
+            n_block = within / Gl;
+            pair = (g * G + within % Gl) * 8 + x;
         } else {
             const int Lr = L - full;
             pair = (P / 8) * 8 + Lr / n_kblocks;
@@ -221,14 +233,17 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // P = exp2(S * c) needs no second operand (measured: +2.5 % at d = 128; at d = 64, where the
     // short S chain then waits on that LDS read, -13 %).
     constexpr bool LSE_IN_ACC = DP >= 128;
-    // Step -> (query head of the GQA group, 32-row slice).  Slices are swept from the last one
-    // down: under a causal mask every key block sees the last rows, so the co-resident blocks of
-    // a pair read the same slice at about the same time.  Kept as counters (an integer division
-    // per step costs more scalar/vector instructions than the step's address arithmetic).
+    // Step -> (32-row slice, query head of the GQA group).  Slices are swept from the last one
+    // down, and all heads of the group take a slice before the next slice: under a causal mask
+    // every key block sees the last rows, so the co-resident blocks of a pair read the same
+    // (slice, head) at about the same time and share it through L2 -- head-major order lets the
+    // shorter sweeps of the later key blocks run ahead onto other heads (measured with 4 heads per
+    // group, b4 s4096 d128 causal: see the dK/dV figures in the design notes).  Kept as counters (an
+    // integer division per step costs more instructions than the step's address arithmetic).
     auto advance = [&](int &hh_, int &m_) {
-        if (--m_ < m_min) {
-            m_ = m_max - 1;
-            ++hh_;
+        if (++hh_ == p.h_ratio) {
+            hh_ = 0;
+            --m_;
         }
     };
     // FAST: Q / dO rows come through buffer loads whose descriptor (rebuilt per head, it is four
@@ -619,7 +634,8 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
 
-    // block -> (batch, head, m_block): whole (batch, kv head) pairs per XCD, heavy m-blocks first
+    // block -> (batch, head, m_block): whole (batch, kv head) pairs per XCD; within an XCD, groups
+    // of G pairs with the m-blocks heaviest first across the group's pairs (as in the forward)
     int bidb, bidh, m_block;
     {
         const int g = p.h_ratio;
@@ -627,20 +643,29 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
         const int P = p.b * p.h_k;
         const int L = blockIdx.x;
         const int full = (P / 8) * 8 * W;
-        int pair, item;
+        constexpr int SLOTS = 32 * ((NW == 8 || DP == 256) ? 1 : 2);
+        int pair, head, mi;
         if (L < full) {
             const int x = L & 7, s = L >> 3;
-            pair = (s / W) * 8 + x;
-            item = s % W;
+            const int ppx = P / 8;
+            const int G = max(1, min(ppx, (2 * SLOTS + W - 1) / W));
+            const int grp = s / (G * W);
+            const int within = s - grp * G * W;
+            const int Gl = min(G, ppx - grp * G);
+            mi = within / (Gl * g);
+            const int rest = within - mi * (Gl * g);
+            pair = (grp * G + rest / g) * 8 + x;
+            head = rest % g;
         } else {
             const int Lr = L - full;
             pair = (P / 8) * 8 + Lr / W;
-            item = Lr % W;
+            const int item = Lr % W;
+            head = item % g;
+            mi = item / g;
         }
         bidb = pair / p.h_k;
-        const int hk_ = pair % p.h_k;
-        bidh = hk_ * g + item % g;
-        m_block = n_mblocks - 1 - item / g;
+        bidh = (pair % p.h_k) * g + head;
+        m_block = n_mblocks - 1 - mi;
     }
     const int hk = bidh / p.h_ratio;
     const BlockInfo bi(p, bidb);

@@ -57,28 +57,41 @@ struct PrefillCfg {
 
 // block -> (batch, head, m_block).  Blocks b and b+8 share an XCD (round-robin dispatch), so give
 // each XCD whole (batch, kv-head) pairs: their K/V then stay in that XCD's L2 while the pair's
-// query heads and m-blocks stream through.  Heaviest m-blocks (causal) first.
-__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, int &bidb, int &bidh,
-                                          int &m_block) {
+// query heads and m-blocks stream through.  Within an XCD the pairs are taken in groups of G, and
+// within a group the m-blocks go heaviest first ACROSS its pairs (the last m-block of every pair,
+// then the one before, ...): under a causal mask m-block m costs (m + 1) tiles, and pair-by-pair
+// order starts the heavy blocks of the next pair only as the light ones of this pair finish, which
+// shows as a tail of up to one heavy block per CU.  G covers about two rounds of the XCD's
+// `slots` resident workgroups, so the co-resident blocks still come from few pairs.
+__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, const int slots, int &bidb,
+                                          int &bidh, int &m_block) {
     const int g = p.h_ratio;
     const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
     const int P = p.b * p.h_k;
     const int L = blockIdx.x;
     const int full = (P / 8) * 8 * W;
-    int pair, item;
+    int pair, head, mi;
     if (L < full) {
         const int x = L & 7, s = L >> 3;
-        pair = (s / W) * 8 + x;
-        item = s % W;
+        const int ppx = P / 8;
+        const int G = max(1, min(ppx, (2 * slots + W - 1) / W));
+        const int grp = s / (G * W);
+        const int within = s - grp * G * W;
+        const int Gl = min(G, ppx - grp * G);
+        mi = within / (Gl * g);
+        const int rest = within - mi * (Gl * g);
+        pair = (grp * G + rest / g) * 8 + x;
+        head = rest % g;
     } else {
         const int Lr = L - full;
         pair = (P / 8) * 8 + Lr / W;
-        item = Lr % W;
+        const int item = Lr % W;
+        head = item % g;
+        mi = item / g;
     }
     bidb = pair / p.h_k;
-    const int hk = pair % p.h_k;
-    bidh = hk * g + item % g;
-    m_block = n_mblocks - 1 - item / g;
+    bidh = (pair % p.h_k) * g + head;
+    m_block = n_mblocks - 1 - mi;
 }
 
 // FAST: K/V are contiguous per (batch, head) (no block table) and fit a 32-bit byte offset, so
@@ -104,7 +117,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     const int r = lane & 31, hh = lane >> 5;
 
     int bidb, bidh, m_block;
-    map_block(p, n_mblocks, bidb, bidh, m_block);
+    map_block(p, n_mblocks, 32 * ((NW == 8 || DP == 256) ? 1 : 2), bidb, bidh, m_block);
     const int hk = bidh / p.h_ratio;
 
     const BlockInfo bi(p, bidb);
