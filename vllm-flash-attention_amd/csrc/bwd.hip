@@ -908,10 +908,12 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     if (ev) (void)hipEventRecord(ev[2], stream);
     {
         // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU: measured
-        // on MI355X, 4 waves win under a causal / window mask up to seqlen 2048 (d = 128) or 4096
-        // (d = 64) by 3..25 %, and without a mask below seqlen 2048; 8 waves win by 3..7 % beyond.
+        // on MI355X (16k tokens, seqlen 512..16k): at d = 64, 4 waves win under a causal / window
+        // mask up to seqlen 4096 (by up to 7 %) and without a mask below 2048; at d = 128, 8 waves
+        // are equal or better (1..4 %) from seqlen 512 without a mask and from 1024 with one.
         const bool masked = p.is_causal || p.is_local;
-        const bool big = masked ? p.seqlen_q >= (DP == 64 ? 8192 : 4096) : p.seqlen_q >= 2048;
+        const bool big = DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
+                                  : (masked ? p.seqlen_q >= 1024 : p.seqlen_q >= 512);
         if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
         else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);

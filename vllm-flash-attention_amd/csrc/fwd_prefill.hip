@@ -593,11 +593,11 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) against two
     // independent 4-wave blocks per CU, which overlap each other's prologue / epilogue / barrier
     // stalls and split a causal diagonal more finely.  Measured on MI355X (bf16, 16k..64k tokens,
-    // seqlen 1k..16k): d = 64 is faster with 4 waves everywhere (+8..40 %); d = 128 without a mask
+    // seqlen 512..16k): d = 64 is faster with 4 waves everywhere (+8..40 %); d = 128 without a mask
     // is faster with 8 waves everywhere measured (+3..9 %); d = 128 causal / windowed crosses over
-    // between seqlen 4096 (equal) and 8192 (+8 % for 8 waves).
+    // between seqlen 2048 (equal) and 4096 (+3 % for 8 waves; +5 % at 16k).
     const bool masked = p.is_causal || p.is_local;
-    const bool big = masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 1024;
+    const bool big = masked ? p.seqlen_q >= 4096 : p.seqlen_q >= 512;
     if (p.d <= 64) {
         return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
     } else if (p.d <= 128) {
