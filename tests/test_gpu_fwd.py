@@ -186,6 +186,44 @@ def test_varlen_paged_vs_oracle():
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("d,page,sq", [(128, 16, 300), (128, 64, 700), (128, 256, 4200), (128, 32, 4200),
+                                       (64, 32, 500), (64, 16, 500), (256, 16, 260), (128, 48, 300)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_paged_prefill_equals_contiguous(d, page, sq, causal):
+    """Prefill over a paged cache must give the bits of the same call on contiguous K/V: covers the
+    per-page buffer-descriptor loads (power-of-two pages holding whole load rounds) and the
+    per-row path (small or odd pages), ragged lengths that end inside a page, NaN in every cache
+    row past a sequence's end and in unused pages, and garbage in unused block-table entries."""
+    import vllm_flash_attn as fa
+    torch.manual_seed(d + page)
+    h, hk = 4, 2
+    kl = [sq, sq - page // 2 - 3, 37]
+    ql = [sq, 129, 37]
+    b = len(kl)
+    maxblk = (max(kl) + page - 1) // page + 2
+    nblocks = b * maxblk + 3
+    k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.bfloat16)
+    kc = torch.full((nblocks, page, hk, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    vc = torch.full_like(kc, float("nan"))
+    perm = torch.randperm(nblocks)[: b * maxblk].reshape(b, maxblk).to(torch.int32)
+    bt = perm.clone()
+    off = 0
+    for i, n in enumerate(kl):
+        for j in range((n + page - 1) // page):
+            rows = min(page, n - j * page)
+            kc[perm[i, j], :rows] = k[off + j * page: off + j * page + rows]
+            vc[perm[i, j], :rows] = v[off + j * page: off + j * page + rows]
+        bt[i, (n + page - 1) // page:] = 2 ** 30  # never dereferenced
+        off += n
+    cq, ck = _cu(ql), _cu(kl)
+    ref = fa.flash_attn_varlen_func(q, k, v, cq, ck, max(ql), max(kl), causal=causal)
+    out = fa.flash_attn_varlen_func(q, kc, vc, cq, ck, max(ql), max(kl), causal=causal, block_table=bt.cuda())
+    assert not torch.isnan(out).any()
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("interleaved", [True, False])
 @pytest.mark.parametrize("paged", [False, True])
 def test_kvcache_append_rotary_vs_oracle(interleaved, paged):

@@ -94,17 +94,23 @@ __device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks,
     m_block = n_mblocks - 1 - mi;
 }
 
-// FAST: K/V are contiguous per (batch, head) (no block table) and fit a 32-bit byte offset, so
+// LD = 1: K/V are contiguous per (batch, head) (no block table) and fit a 32-bit byte offset, so
 // tiles are fetched with buffer loads whose descriptor ends at the last valid key row: the key
 // tail and the head-dim padding read as zeros without any predication or 64-bit address
 // arithmetic in the tile loop.
+// LD = 2: paged K/V whose page size is a power of two and a multiple of the NT / CPR rows that
+// the workgroup's threads cover per load round: the rows of one round then lie in ONE page, its
+// id is a scalar, and the round is a buffer load through a descriptor built (in scalar registers)
+// at that page's rows and ending at the page's or the sequence's last row.
+// LD = 0: generic per-row addressing (any strides, any page size).
 //
 // DROP: dropout on P (flash_fwd_kernel.h:324-337, dropout.h) with the reference's Philox pattern,
 // and the optional Return_softmax output.  The reference point of the exponentials then follows
 // the running maximum exactly (tile by tile, like the reference), because S_dmask exposes it.
-template <int DP, bool BF16, int NW, bool FAST, bool DROP>
+template <int DP, bool BF16, int NW, int LD, bool DROP>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
+    constexpr bool FAST = LD == 1, PAGED_BUF = LD == 2;
     using Cfg = PrefillCfg<DP, BF16, NW>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
     constexpr int KS = DP / 16;   // k-steps of QK^T
@@ -182,8 +188,18 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     // Paged KV: the page ids of a tile are fetched one tile ahead of its rows, so that the
     // block-table lookup is not a second memory latency in front of the K/V loads.
     int pg[FAST ? 1 : CH];
+    constexpr int RSTEP = NT / CPR;  // rows between a lane's chunks = rows of one load round
     auto load_pages = [&](int n) {
-        if constexpr (!FAST) {
+        if constexpr (PAGED_BUF) {
+            if (n < 0) return;
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int rb = n * BN + RSTEP * i;  // first row of round i: uniform
+                // (kept in a vector register until the tile is loaded, one tile later: moving it to
+                // a scalar register here would wait for the K/V loads issued just before)
+                pg[i] = bt[(rb < sk ? rb : 0) >> p.page_shift];
+            }
+        } else if constexpr (!FAST) {
             if (!bt || n < 0) return;
 #pragma unroll
             for (int i = 0; i < CH; i++) {
@@ -195,13 +211,30 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     };
     auto load_tile = [&](int n) {
         if constexpr (FAST) {
-            constexpr int RSTEP = NT / CPR;  // rows between a lane's chunks
 #pragma unroll
             for (int i = 0; i < CH; i++) {
                 kreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     k_rsrc, k_voff + (unsigned)(n * BN + RSTEP * i) * k_rs2, 0, 0));
                 vreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     v_rsrc, v_voff + (unsigned)(n * BN + RSTEP * i) * v_rs2, 0, 0));
+            }
+            return;
+        }
+        if constexpr (PAGED_BUF) {
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int rb = n * BN + RSTEP * i;
+                const int inpage = rb & (p.page_size - 1);
+                const int pgi = __builtin_amdgcn_readfirstlane(pg[i]);
+                const int valid = min(sk - rb, p.page_size - inpage);  // rows of this round that exist
+                const unsigned kb_ = valid > 0 ? (unsigned)(((int64_t)(valid - 1) * p.k_rs + p.d) * 2) : 0u;
+                const unsigned vb_ = valid > 0 ? (unsigned)(((int64_t)(valid - 1) * p.v_rs + p.d) * 2) : 0u;
+                const auto kr_ = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(kg + (int64_t)pgi * p.k_bs + (int64_t)inpage * p.k_rs), 0, kb_, 0x00020000);
+                const auto vr_ = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(vg + (int64_t)pgi * p.v_bs + (int64_t)inpage * p.v_rs), 0, vb_, 0x00020000);
+                kreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(kr_, k_voff, 0, 0));
+                vreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(vr_, v_voff, 0, 0));
             }
             return;
         }
@@ -555,13 +588,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
+template <int DP, bool BF16, int NW, int LD, bool DROP = false>
 static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_prefill_kernel<DP, BF16, NW, FAST, DROP>;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP>;
     if (Cfg::LDS_BYTES > 64 * 1024) {  // per device and cheap: set on every launch
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -581,10 +614,21 @@ static bool kv_fits_buffer(const KParams &p) {
     return rows * p.k_rs * 2 < lim && rows * p.v_rs * 2 < lim;
 }
 
+// Paged K/V with power-of-two pages that hold whole load rounds (NT / CPR rows) take per-page
+// buffer descriptors.
+template <int DP, int NW>
+static bool paged_fits_buffer(const KParams &p) {
+    constexpr int RSTEP = NW * 64 / (DP / 8);
+    const int64_t lim = (int64_t)1 << 30;
+    return p.block_table && p.page_shift >= 0 && p.page_size % RSTEP == 0 &&
+           (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
+}
+
 template <int DP, bool BF16, int NW>
 static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
-    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, NW, true>(p, stream)
-                             : launch_prefill_impl<DP, BF16, NW, false>(p, stream);
+    if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, 1>(p, stream);
+    if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2>(p, stream);
+    return launch_prefill_impl<DP, BF16, NW, 0>(p, stream);
 }
 
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
@@ -613,13 +657,13 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
 hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
     if (p.d <= 64)
-        return bf ? launch_prefill_impl<64, true, 4, false, true>(p, stream)
-                  : launch_prefill_impl<64, false, 4, false, true>(p, stream);
+        return bf ? launch_prefill_impl<64, true, 4, 0, true>(p, stream)
+                  : launch_prefill_impl<64, false, 4, 0, true>(p, stream);
     if (p.d <= 128)
-        return bf ? launch_prefill_impl<128, true, 4, false, true>(p, stream)
-                  : launch_prefill_impl<128, false, 4, false, true>(p, stream);
-    return bf ? launch_prefill_impl<256, true, 4, false, true>(p, stream)
-              : launch_prefill_impl<256, false, 4, false, true>(p, stream);
+        return bf ? launch_prefill_impl<128, true, 4, 0, true>(p, stream)
+                  : launch_prefill_impl<128, false, 4, 0, true>(p, stream);
+    return bf ? launch_prefill_impl<256, true, 4, 0, true>(p, stream)
+              : launch_prefill_impl<256, false, 4, 0, true>(p, stream);
 }
 #endif  // VFA_DROPOUT_TU
 
