@@ -302,6 +302,16 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     float alibi = 0.f;
     const bool has_alibi = p.alibi_slopes != nullptr;
     if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
+    // ALiBi in LINEAR form.  Under a causal mask, or a window that ends at the diagonal or before,
+    // every visible key has col <= row + sk - sq, so the bias -slope |row + sk - sq - col| is
+    // slope * col plus a constant of the row, and a constant of the row cancels in the softmax.
+    // The kernel then adds alibi * (col - cref), cref = the block's first diagonal column (small
+    // magnitudes), which is one multiply-add against a compile-time key offset per score, and
+    // puts the row constant back into the returned LSE: + slope * cref in causal mode, where the
+    // reference itself adds slope * col (mask.h:180-181), - slope * (row + sk - sq - cref) under
+    // a window (mask.h:183).
+    const bool alibi_lin = has_alibi && (p.is_causal || (p.is_local && p.wr <= 0));
+    const int cref = m_block * BM + sk - sq;
     const float c2 = p.scale_log2;
 
     // per-lane LDS read offsets (see the note at st_off)
@@ -356,9 +366,10 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         // the maximum of the first 32 keys and the exponentials of the first 16, taken against the
         // current reference point, go with the MFMAs of the second 32 keys.  They stand unless the
         // tile needs a mask or moves the reference point (both rare), which redoes them.
-        bool need = has_alibi || (c0 + BN > sk);
-        if (p.is_causal || p.is_local) need = need || (c0 + BN > q0w + 1 + sk - sq + p.wr);
-        if (p.is_local) need = need || (c0 < q0w + 31 + sk - sq - p.wl);
+        bool need_mask = c0 + BN > sk;
+        if (p.is_causal || p.is_local) need_mask = need_mask || (c0 + BN > q0w + 1 + sk - sq + p.wr);
+        if (p.is_local) need_mask = need_mask || (c0 < q0w + 31 + sk - sq - p.wl);
+        const bool need = need_mask || has_alibi;
         f32x16 s[2];
         i32x4 pf[4];
         float ps[4] = {0.f, 0.f, 0.f, 0.f};  // four short row-sum chains instead of one of 32 adds
@@ -433,6 +444,19 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
                 for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
             }
+        } else if (alibi_lin && !need_mask) {
+            // interior tile: bias only
+            const float t = alibi * (float)(c0 + 4 * hh - cref);
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; kb2++)
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    s[kb2][j] = __builtin_fmaf(alibi, (float)(32 * kb2 + (j & 3) + 8 * (j >> 2)), s[kb2][j] + t);
+            if constexpr (SPEC) {
+                mx = s[0][0];
+#pragma unroll
+                for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
+            }
         } else if (need) {
             const int row = q0w + r;
             const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
@@ -444,8 +468,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                     const int col = c0 + 32 * kb2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
                     float x = s[kb2][j];
                     if (has_alibi)
-                        x = p.is_causal ? x + alibi * (float)col
-                                        : x - alibi * fabsf((float)(row + sk - sq - col));
+                        x = alibi_lin ? x + alibi * (float)(col - cref)
+                                      : x - alibi * fabsf((float)(row + sk - sq - col));
                     s[kb2][j] = (col >= lo && col < hi) ? x : -INFINITY;
                 }
             if constexpr (SPEC) {
@@ -562,7 +586,11 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     const float l_tot = half_swap_sum(l_run);
     const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
     const float inv = (bad ? 1.f : 1.f / l_tot) * (DROP ? p.rp_dropout : 1.f);  // softmax.h:181
-    const float lse = bad ? INFINITY : m_run * p.scale + __logf(l_tot);
+    float lse = bad ? INFINITY : m_run * p.scale + __logf(l_tot);
+    if (alibi_lin && !bad) {  // the row constant left out of the linear ALiBi form
+        const float slope = alibi * p.scale;
+        lse += p.is_causal ? slope * (float)cref : -slope * (float)(q0w + r + sk - sq - cref);
+    }
     if (hh == 0 && q0w + r < sq) lse_g[q0w + r] = lse;
 
     // (the loop's last __syncthreads() already fenced all LDS reads of the K/V tiles)
