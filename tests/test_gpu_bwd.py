@@ -210,3 +210,32 @@ def test_huge_row_stride_takes_the_generic_load_path():
         g1 = cabi.bwd(do, q, ks, vs, out0, lse0, causal=causal)
         for a, c in zip(g0[:3], g1[:3]):
             assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("b,h,hk,sq,sk,d", [(8, 4, 1, 300, 300, 128), (9, 2, 1, 520, 520, 64), (3, 12, 3, 257, 400, 128),
+                                            (17, 4, 2, 130, 130, 64), (5, 16, 8, 1100, 1100, 128),
+                                            (2, 8, 8, 4200, 4200, 128), (40, 1, 1, 64, 700, 128)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_block_order_covers_every_block(b, h, hk, sq, sk, d, causal):
+    """The block -> (batch, head, row / key block) maps take (batch, kv head) pairs in groups per
+    XCD with a heaviest-first order across each group: with pair counts that do and do not divide
+    by 8, groups that do not divide the pairs of an XCD, and several heads per kv head, every output
+    element must still be produced exactly once -- the full batch against one call per batch
+    element (bitwise), outputs pre-filled with NaN."""
+    import cabi
+    torch.manual_seed(b * 100 + h)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn_like(q)
+    out = torch.full_like(q, float("nan"))
+    out, lse = cabi.fwd(q, k, v, causal=causal, out=out)
+    dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, causal=causal)
+    for t in (out, dq, dk, dv):
+        assert not torch.isnan(t).any()
+    for i in range(b):
+        s_ = slice(i, i + 1)
+        o1, l1 = cabi.fwd(q[s_], k[s_], v[s_], causal=causal)
+        assert torch.equal(o1, out[s_]) and torch.equal(l1, lse[s_])
+        g1 = cabi.bwd(do[s_], q[s_], k[s_], v[s_], o1, l1, causal=causal)
+        assert torch.equal(g1[0], dq[s_]) and torch.equal(g1[1], dk[s_]) and torch.equal(g1[2], dv[s_])
