@@ -540,3 +540,44 @@ def test_decode_is_graph_capturable():
     ref = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True, num_splits=1)
     assert torch.equal(got_c, ref)
     assert (got_p.float() - ref.float()).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("d,sq,sk,splits,causal,paged", [
+    (128, 200, 1000, 2, True, False), (128, 130, 4100, 5, False, False), (64, 513, 2000, 3, True, False),
+    (256, 100, 700, 4, True, False), (128, 300, 1500, 3, True, True), (64, 90, 900, 7, False, True),
+    (128, 65, 257, 4, True, False)])
+def test_split_kv_with_many_query_rows(d, sq, sk, splits, causal, paged):
+    """num_splits > 1 with more than 64 query rows runs the prefill kernel's split variants +
+    the combine kernel (a few hundred new tokens against a long context): against the oracle's
+    split + combine and against the unsplit call; ragged second sequence, splits that see no key
+    (causal, short sequence), GQA, paged cache."""
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(sq + sk)
+    b, h, hk, page = 2, 4, 2, 32
+    lens = torch.tensor([sk, max(1, sk // 3)], dtype=torch.int32, device="cuda")
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    kw = dict(causal=causal, cache_seqlens=lens)
+    okw = dict(dtype="bf16", causal=causal, cache_seqlens=lens.cpu().numpy())
+    kk, vv = k, v
+    if paged:
+        nblk = (sk + page - 1) // page
+        perm = torch.randperm(b * nblk, device="cuda").reshape(b, nblk).to(torch.int32)
+        kk = torch.zeros(b * nblk, page, hk, d, device="cuda", dtype=torch.bfloat16)
+        vv = torch.zeros_like(kk)
+        pad = nblk * page - sk
+        kk[perm.flatten().long()] = torch.nn.functional.pad(k, (0, 0, 0, 0, 0, pad)).reshape(b * nblk, page, hk, d)
+        vv[perm.flatten().long()] = torch.nn.functional.pad(v, (0, 0, 0, 0, 0, pad)).reshape(b * nblk, page, hk, d)
+        kw["block_table"] = perm
+        okw["block_table"] = perm.cpu().numpy()
+    out1, lse1 = _cabi().fwd(q, kk, vv, num_splits=1, **kw)
+    outs, lses = _cabi().fwd(q, kk, vv, num_splits=splits, **kw)
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(kk), f32(vv), num_splits=splits, block_n=64, block_m=128, **okw)
+    assert np.abs(f32(outs) - ro).max() <= ulp_tol("bf16", ro)
+    assert np.abs(f32(outs) - f32(out1)).max() <= ulp_tol("bf16", ro)
+    fin = np.isfinite(rl)
+    assert np.array_equal(np.isposinf(f32(lses)), np.isposinf(rl))
+    assert np.abs(f32(lses)[fin] - rl[fin]).max() <= 1e-3
+    assert np.abs(f32(lses)[fin] - f32(lse1)[fin]).max() <= 1e-3

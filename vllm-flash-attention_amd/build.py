@@ -23,9 +23,10 @@ OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
-               "bwd_drop.hip"]
+               "bwd_drop.hip", "fwd_prefill_split.hip"]
 # the dropout translation units are one-line includes of the kernel sources
-EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"]}
+EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"],
+              "fwd_prefill_split.hip": ["fwd_prefill.hip"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
 

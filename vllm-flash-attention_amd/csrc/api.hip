@@ -18,6 +18,9 @@ hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream);
 hipError_t run_append_kv(const KParams &p, hipStream_t stream);
 hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
 hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream);
+hipError_t run_fwd_prefill_split(const KParams &p, hipStream_t stream);
+bool fwd_prefill_split_ok(const KParams &p);
+hipError_t run_fwd_combine(const KParams &p, hipStream_t stream);
 hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
 }  // namespace vfa
 
@@ -159,9 +162,20 @@ extern "C" int vfa_num_splits_heuristic(int batch_nheads_mblocks, int num_sms, i
 
 extern "C" int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, int max_seqlen_k,
                                       int max_seqlen_q, int num_cus_) {
-    // flash_api.cpp:199-210.  The work items of the split kernel here are (batch, kv head,
-    // 64-row block) with 64-key tiles... the block sizes below follow the reference so that the
-    // split count (and therefore the scratch shapes callers allocate) is the same function.
+    // flash_api.cpp:199-210.  Up to 64 query rows (decode) the block sizes follow the reference,
+    // so the split count is the same function of the shapes as the reference's.
+    if (max_seqlen_q > 64) {
+        // Beyond 64 query rows the split work items are the prefill kernel's 128-row blocks.  Their
+        // fp32 partial results cost HBM traffic in proportion to rows x splits, so splitting is
+        // kept for launches that would otherwise fill at most a quarter of the resident-workgroup
+        // slots, and every split gets at least 16 tiles (1024 keys).  Measured on MI355X (h32/8
+        // d128): 512 rows against 8192 keys, batch 1: 195 -> 116 us; 1024 x 1024: 30 -> 77 us (not
+        // split under this rule).
+        const int blocks = batch * num_heads * ((max_seqlen_q + 127) / 128);
+        const int chunks = ((max_seqlen_k + 63) / 64) / 16;
+        if (blocks * 4 > num_cus_ * 2 || chunks < 2) return 1;
+        return vfa_num_splits_heuristic(blocks, num_cus_ * 2, chunks, 128);
+    }
     const int block_n = head_size <= 64 ? 256 : (head_size <= 128 ? 128 : 64);
     const int num_n_blocks = (max_seqlen_k + block_n - 1) / block_n;
     const int num_m_blocks = (max_seqlen_q + 64 - 1) / 64;
@@ -197,7 +211,14 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
         k.num_splits = p->num_splits;
         k.oaccum = p->oaccum;
         k.lseaccum = p->softmax_lseaccum;
-        e = vfa::run_fwd_splitkv(k, stream);
+        // Few query rows: the decode kernel (waves split the keys of a 32-row block).  More: the
+        // prefill kernel's split variants (128-row blocks), when they can load this K/V layout.
+        if (k.seqlen_q > 64 && vfa::fwd_prefill_split_ok(k)) {
+            e = vfa::run_fwd_prefill_split(k, stream);
+            if (e == hipSuccess) e = vfa::run_fwd_combine(k, stream);
+        } else {
+            e = vfa::run_fwd_splitkv(k, stream);
+        }
         if (e != hipSuccess) return hip_fail(e, "splitkv launch");
         return VFA_OK;
     }

@@ -107,7 +107,12 @@ __device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks,
 // DROP: dropout on P (flash_fwd_kernel.h:324-337, dropout.h) with the reference's Philox pattern,
 // and the optional Return_softmax output.  The reference point of the exponentials then follows
 // the running maximum exactly (tile by tile, like the reference), because S_dmask exposes it.
-template <int DP, bool BF16, int NW, int LD, bool DROP>
+//
+// SPLIT: blockIdx.y cuts the key range into p.num_splits parts (flash_fwd_kernel.h:504-512); every
+// part writes its normalised fp32 O and its LSE (-inf if it saw no key, :513-552) to p.oaccum /
+// p.lseaccum and fwd_combine_kernel merges them.  For launches whose (batch, head, row-block)
+// count alone would leave most CUs idle: a few hundred query rows against a long context.
+template <int DP, bool BF16, int NW, int LD, bool DROP, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     constexpr bool FAST = LD == 1, PAGED_BUF = LD == 2;
@@ -148,17 +153,34 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
                          (int64_t)bidh * p.o_hs;
     float *lse_g = p.lse + ((int64_t)bidb * p.h + bidh) * p.seqlen_q;
+    float *oacc_g = nullptr;
+    if constexpr (SPLIT) {
+        const int split = blockIdx.y;
+        const int per = (((p.seqlen_k + BN - 1) / BN) + p.num_splits - 1) / p.num_splits;  // from the capacity
+        n_min = max(n_min, split * per);
+        n_max = min(n_max, (split + 1) * per);
+        const int64_t acc_row0 = (((int64_t)split * p.b + bidb) * p.h + bidh) * p.seqlen_q;
+        lse_g = p.lseaccum + acc_row0;
+        oacc_g = p.oaccum + acc_row0 * p.d;
+    }
     const int q0w = m_block * BM + wave * 32;  // first query row of this wave
 
     if (n_max <= n_min) {
-        // No visible key for this row block: O = 0, LSE = +inf (flash_fwd_kernel.h:70-106).
+        // No visible key for this row block: O = 0, LSE = +inf (flash_fwd_kernel.h:70-106);
+        // a split that sees none: partial O = 0, LSE = -inf (:513-552).
         for (int c = tid; c < BM * CPR; c += NT) {
             const int row = m_block * BM + c / CPR, ch = c % CPR;
-            if (row < sq && ch * 8 < p.d)
-                *(i32x4 *)(og + (int64_t)row * p.o_rs + ch * 8) = i32x4{0, 0, 0, 0};
+            if (row < sq && ch * 8 < p.d) {
+                if constexpr (SPLIT) {
+                    *(f32x4 *)(oacc_g + (int64_t)row * p.d + ch * 8) = f32x4{0, 0, 0, 0};
+                    *(f32x4 *)(oacc_g + (int64_t)row * p.d + ch * 8 + 4) = f32x4{0, 0, 0, 0};
+                } else {
+                    *(i32x4 *)(og + (int64_t)row * p.o_rs + ch * 8) = i32x4{0, 0, 0, 0};
+                }
+            }
         }
         for (int c = tid; c < BM; c += NT)
-            if (m_block * BM + c < sq) lse_g[m_block * BM + c] = INFINITY;
+            if (m_block * BM + c < sq) lse_g[m_block * BM + c] = SPLIT ? -INFINITY : INFINITY;
         return;
     }
 
@@ -586,13 +608,30 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     const float l_tot = half_swap_sum(l_run);
     const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
     const float inv = (bad ? 1.f : 1.f / l_tot) * (DROP ? p.rp_dropout : 1.f);  // softmax.h:181
-    float lse = bad ? INFINITY : m_run * p.scale + __logf(l_tot);
+    float lse = bad ? (SPLIT ? -INFINITY : INFINITY) : m_run * p.scale + __logf(l_tot);
     if (alibi_lin && !bad) {  // the row constant left out of the linear ALiBi form
         const float slope = alibi * p.scale;
         lse += p.is_causal ? slope * (float)cref : -slope * (float)(q0w + r + sk - sq - cref);
     }
     if (hh == 0 && q0w + r < sq) lse_g[q0w + r] = lse;
 
+    if constexpr (SPLIT) {
+        // fp32 partial result straight from the accumulators: lane (r, hh) holds, per d block and
+        // group g4, four consecutive columns of row q0w + r
+        if (q0w + r < sq) {
+            float *dst = oacc_g + (int64_t)(q0w + r) * p.d;
+#pragma unroll
+            for (int db = 0; db < NDB; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int col = 32 * db + 8 * g4 + 4 * hh;
+                    if (col < p.d)
+                        *(f32x4 *)(dst + col) = f32x4{o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
+                                                      o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv};
+                }
+        }
+        return;
+    }
     // (the loop's last __syncthreads() already fenced all LDS reads of the K/V tiles)
     char *ob = smem + wave * 32 * Cfg::O_ROWB;
 #pragma unroll
@@ -616,24 +655,24 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
-template <int DP, bool BF16, int NW, int LD, bool DROP = false>
+template <int DP, bool BF16, int NW, int LD, bool DROP = false, bool SPLIT = false>
 static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP>;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP, SPLIT>;
     if (Cfg::LDS_BYTES > 64 * 1024) {  // per device and cheap: set on every launch
         hipError_t e = hipFuncSetAttribute((const void *)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p,
-                       n_mblocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SPLIT ? (unsigned)p.num_splits : 1u), dim3(Cfg::NT),
+                       Cfg::LDS_BYTES, stream, p, n_mblocks);
     return hipGetLastError();
 }
 
-#ifndef VFA_DROPOUT_TU
+#if !defined(VFA_DROPOUT_TU) || defined(VFA_SPLIT_TU)
 // Contiguous K/V whose per-(batch, head) extent fits a 32-bit buffer offset take the buffer-load path.
 static bool kv_fits_buffer(const KParams &p) {
     if (p.block_table) return false;
@@ -652,6 +691,8 @@ static bool paged_fits_buffer(const KParams &p) {
            (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
 }
 
+#endif
+#if !defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)
 template <int DP, bool BF16, int NW>
 static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, 1>(p, stream);
@@ -680,6 +721,24 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     }
 }
 
+#elif defined(VFA_SPLIT_TU)
+// Split-KV variants (4 waves; contiguous or buffer-paged K/V), a translation unit of their own.
+template <int DP, bool BF16>
+static hipError_t launch_prefill_split(const KParams &p, hipStream_t stream) {
+    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, 1, false, true>(p, stream)
+                             : launch_prefill_impl<DP, BF16, 4, 2, false, true>(p, stream);
+}
+// Whether the split variants can load this K/V layout (else the caller takes the decode kernel).
+bool fwd_prefill_split_ok(const KParams &p) {
+    if (kv_fits_buffer(p)) return true;
+    return p.d <= 64 ? paged_fits_buffer<64, 4>(p) : (p.d <= 128 ? paged_fits_buffer<128, 4>(p) : paged_fits_buffer<256, 4>(p));
+}
+hipError_t run_fwd_prefill_split(const KParams &p, hipStream_t stream) {
+    const bool bf = p.is_bf16;
+    if (p.d <= 64) return bf ? launch_prefill_split<64, true>(p, stream) : launch_prefill_split<64, false>(p, stream);
+    if (p.d <= 128) return bf ? launch_prefill_split<128, true>(p, stream) : launch_prefill_split<128, false>(p, stream);
+    return bf ? launch_prefill_split<256, true>(p, stream) : launch_prefill_split<256, false>(p, stream);
+}
 #else   // VFA_DROPOUT_TU: the dropout variants are compiled as a translation unit of their own
 // Dropout is a training feature: one geometry (4 waves, generic loads) per head dim.
 hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream) {

@@ -513,6 +513,16 @@ static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
     return e;
 }
 
+// The merge alone, for split partial results written by another kernel (the prefill kernel's
+// split variants).
+hipError_t run_fwd_combine(const KParams &p, hipStream_t stream) {
+    const unsigned cblocks = (unsigned)((long long)p.b * p.h * p.seqlen_q);
+    if (cblocks == 0) return hipSuccess;
+    if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_kernel<true>, dim3(cblocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(fwd_combine_kernel<false>, dim3(cblocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
     if (p.d <= 64) return bf ? launch_decode<64, true>(p, stream) : launch_decode<64, false>(p, stream);
