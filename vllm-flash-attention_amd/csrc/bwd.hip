@@ -734,6 +734,35 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
                 *(i32x4 *)(vb + off) = vreg[i];
             }
         };
+        // DIRECT: the buffer loads write LDS themselves (buffer_load_dwordx4 ... lds), 1 KiB per
+        // wave instruction in lane order: each lane fetches the chunk the XOR swizzle places at its
+        // slot.  No staging registers, no ds_write; vmcnt(0) before the tile's barrier.
+        constexpr bool DIRECT = FAST && DP <= 128;
+        constexpr int RPI = 64 / CPR;
+        constexpr int NI = DIRECT ? DQ_BN / (RPI * NW) : 1;
+        unsigned dk_voff = 0, dv_voff = 0;
+        if constexpr (DIRECT) {
+            const int row0 = RPI * wave + lane / CPR;
+            const int ch = (lane % CPR) ^ swz<DP>(row0);
+            const bool ok = ch * 8 < p.d;
+            dk_voff = ok ? (unsigned)((row0 * (int)p.k_rs + ch * 8) * 2) : 0x80000000u;
+            dv_voff = ok ? (unsigned)((row0 * (int)p.v_rs + ch * 8) * 2) : 0x80000000u;
+        }
+        auto load_tile_direct = [&](int n, int buf) __attribute__((always_inline)) {
+            if constexpr (DIRECT) {
+                typedef __attribute__((address_space(3))) void *lds_ptr;
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const unsigned rows = (unsigned)(n * DQ_BN + RPI * NW * i);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        k_rsrc, (lds_ptr)(smem + buf * Cfg::TILE_BYTES + (wave + NW * i) * 1024), 16,
+                        dk_voff + rows * k_rs2, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        v_rsrc, (lds_ptr)(smem + (2 + buf) * Cfg::TILE_BYTES + (wave + NW * i) * 1024), 16,
+                        dv_voff + rows * v_rs2, 0, 0, 0);
+                }
+            }
+        };
 
         // Q^T and dO^T B-operand fragments; LSE and delta of this lane's query row
         i32x4 qf[KS], dof[KS];
@@ -768,13 +797,21 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
         const float c2 = p.scale_log2;
         const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
 
-        load_tile(n_max - 1);
-        store_tile(0);
+        if constexpr (DIRECT) {
+            load_tile_direct(n_max - 1, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        } else {
+            load_tile(n_max - 1);
+            store_tile(0);
+        }
         __syncthreads();
         int buf = 0;
         for (int n = n_max - 1; n >= n_min; n--) {
             const bool has_next = n > n_min;
-            if (has_next) load_tile(n - 1);
+            if (has_next) {
+                if constexpr (DIRECT) load_tile_direct(n - 1, buf ^ 1);
+                else load_tile(n - 1);
+            }
             const char *kb = smem + buf * Cfg::TILE_BYTES;
             const char *vb = smem + (2 + buf) * Cfg::TILE_BYTES;
             const int c0 = n * DQ_BN;
@@ -843,7 +880,8 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
                     }
                 }
             }
-            if (has_next) store_tile(buf ^ 1);
+            if constexpr (DIRECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier
+            else if (has_next) store_tile(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
