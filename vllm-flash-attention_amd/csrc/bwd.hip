@@ -268,7 +268,12 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // of a step and written to LDS after the first sub-block, chunk 1 is loaded then and written
     // at the end, so one set of staging registers serves both (the registers are what limits the
     // slice height at d = 128).
-    constexpr bool SPLIT = QCH == 2 && QSUB == 2;
+    // DIRECT (buffer-load path, d = 128): the Q / dO slices go from global memory straight into LDS
+    // (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction in lane order, each lane fetching
+    // the chunk the XOR swizzle places at its slot): no staging registers and no ds_write.
+    // Measured on MI355X: -5..7 % kernel time at d = 128, +8 % at d = 64 (kept on registers).
+    constexpr bool DIRECT = FAST && DP == 128;
+    constexpr bool SPLIT = !DIRECT && QCH == 2 && QSUB == 2;
     constexpr int NSTG = SPLIT ? 1 : QCH;  // staging register sets
     i32x4 qreg[NSTG], doreg[NSTG];
     auto load_chunk = [&](const int gh, const int m, const int i, const int slot) {
@@ -291,6 +296,38 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const bool ok = c < BW_QM * CPR && (q0 + row) < sq && ch * 8 < p.d;
             qreg[slot] = ok ? *(const i32x4 *)(qg + (int64_t)(q0 + row) * p.q_rs + ch * 8) : i32x4{0, 0, 0, 0};
             doreg[slot] = ok ? *(const i32x4 *)(dog + (int64_t)(q0 + row) * p.do_rs + ch * 8) : i32x4{0, 0, 0, 0};
+        }
+    };
+    constexpr int RPI = 64 / CPR;                               // rows per wave instruction
+    constexpr int NI = DIRECT ? BW_QM / (RPI * NW) : 1;         // instructions per wave, slice, tensor
+    static_assert(!DIRECT || (BW_QM % (RPI * NW) == 0 && (RPI * NW) % 16 == 0), "direct slice loads");
+    unsigned dq_voff = 0, ddo_voff = 0;
+    if constexpr (DIRECT) {
+        const int row0 = RPI * wave + lane / CPR;
+        const int ch = (lane % CPR) ^ swz<DP>(row0);
+        const bool ok = ch * 8 < p.d;
+        dq_voff = ok ? (unsigned)((row0 * (int)p.q_rs + ch * 8) * 2) : 0x80000000u;
+        ddo_voff = ok ? (unsigned)((row0 * (int)p.do_rs + ch * 8) * 2) : 0x80000000u;
+    }
+    auto load_slice_direct = [&](const int gh, const int m, const int buf) __attribute__((always_inline)) {
+        if constexpr (DIRECT) {
+            typedef __attribute__((address_space(3))) void *lds_ptr;
+            const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
+            const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
+            const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
+            const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)qg, 0, (unsigned)(((int64_t)(sq - 1) * p.q_rs + p.d) * 2), 0x00020000);
+            const auto do_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)dog, 0, (unsigned)(((int64_t)(sq - 1) * p.do_rs + p.d) * 2), 0x00020000);
+            char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const unsigned rows = (unsigned)(q0 + RPI * NW * i);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lds_ptr)(qb + (wave + NW * i) * 1024), 16,
+                                                         dq_voff + rows * (unsigned)p.q_rs * 2, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, (lds_ptr)(qb + Cfg::QT_BYTES + (wave + NW * i) * 1024), 16,
+                                                         ddo_voff + rows * (unsigned)p.do_rs * 2, 0, 0, 0);
+            }
         }
     };
     auto load_rowc = [&](const int gh, const int m) {
@@ -344,10 +381,20 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
 
     int cur_h = 0, cur_m = m_max - 1, nxt_h = 0, nxt_m = m_max - 1;
     advance(nxt_h, nxt_m);
-    if (total_steps > 0) load_slice(cur_h, cur_m);
+    if constexpr (DIRECT) {
+        if (total_steps > 0) load_rowc(cur_h, cur_m);
+    } else {
+        if (total_steps > 0) load_slice(cur_h, cur_m);
+    }
     if (SPLIT && total_steps > 0) load_chunk(cur_h, cur_m, 0, 0);
     __syncthreads();  // every wave has its fragments: the freed tile space becomes the Q buffers
-    if (total_steps > 0) store_slice(0);
+    if constexpr (DIRECT) {
+        if (total_steps > 0) {
+            load_slice_direct(cur_h, cur_m, 0);
+            store_rowc(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    } else if (total_steps > 0) store_slice(0);
     if (SPLIT && total_steps > 0) {
         store_chunk(0, 0, 0);
         load_chunk(cur_h, cur_m, 1, 0);
@@ -365,7 +412,12 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         const bool has_next = step + 1 < total_steps;
         STAMP(7);
         if (has_next) {
-            load_slice(nxt_h, nxt_m);
+            if constexpr (DIRECT) {
+                load_slice_direct(nxt_h, nxt_m, buf ^ 1);
+                load_rowc(nxt_h, nxt_m);
+            } else {
+                load_slice(nxt_h, nxt_m);
+            }
             if constexpr (SPLIT) load_chunk(nxt_h, nxt_m, 0, 0);
         }
         STAMP(0);
@@ -512,9 +564,11 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }  // sub
 
         if (has_next) {
-            store_slice(buf ^ 1);
+            if constexpr (DIRECT) store_rowc(buf ^ 1);
+            else store_slice(buf ^ 1);
             if constexpr (SPLIT) store_chunk(buf ^ 1, 1, 0);
         }
+        if constexpr (DIRECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next slice is in LDS
         STAMP(5);
         __syncthreads();
         STAMP(6);
