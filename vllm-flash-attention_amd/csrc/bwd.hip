@@ -160,9 +160,10 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             n_block = within / Gl;
             pair = (g * G + within % Gl) * 8 + x;
         } else {
-            const int Lr = L - full;
-            pair = (P / 8) * 8 + Lr / n_kblocks;
-            n_block = Lr % n_kblocks;
+            // the last P % 8 pairs, spread over all XCDs: heaviest key blocks first across them
+            const int Lr = L - full, R = P - (P / 8) * 8;
+            pair = (P / 8) * 8 + Lr % R;
+            n_block = Lr / R;
         }
         hk = pair % p.h_k;
         bidb = pair / p.h_k;
@@ -711,11 +712,12 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
             pair = (grp * G + rest / g) * 8 + x;
             head = rest % g;
         } else {
-            const int Lr = L - full;
-            pair = (P / 8) * 8 + Lr / W;
-            const int item = Lr % W;
-            head = item % g;
-            mi = item / g;
+            // the last P % 8 pairs, spread over all XCDs: heaviest m-blocks first across them
+            const int Lr = L - full, R = P - (P / 8) * 8;
+            mi = Lr / (R * g);
+            const int rest = Lr - mi * (R * g);
+            pair = (P / 8) * 8 + rest / g;
+            head = rest % g;
         }
         bidb = pair / p.h_k;
         bidh = (pair % p.h_k) * g + head;

@@ -83,11 +83,12 @@ __device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks,
         pair = (grp * G + rest / g) * 8 + x;
         head = rest % g;
     } else {
-        const int Lr = L - full;
-        pair = (P / 8) * 8 + Lr / W;
-        const int item = Lr % W;
-        head = item % g;
-        mi = item / g;
+        // the last P % 8 pairs, spread over all XCDs: heaviest m-blocks first across them
+        const int Lr = L - full, R = P - (P / 8) * 8;
+        mi = Lr / (R * g);
+        const int rest = Lr - mi * (R * g);
+        pair = (P / 8) * 8 + rest / g;
+        head = rest % g;
     }
     bidb = pair / p.h_k;
     bidh = (pair % p.h_k) * g + head;
