@@ -89,7 +89,8 @@ typedef struct vfa_params {
     float *dsoftmax_sum;             /* (b, h, seqlen_q rounded up to 128) fp32: rowsum(dO * O) */
     float *dq_accum;                 /* unused, may be NULL: kept for the field list of flash.h:153-156
                                         (dQ is accumulated in registers by a query-stationary kernel) */
-    float *dk_accum, *dv_accum;      /* unused, may be NULL (dK/dV of a GQA group are summed in registers) */
+    float *dk_accum, *dv_accum;      /* fp32 partial dK / dV slabs when bwd_head_splits > 1 (below); otherwise
+                                        unused, may be NULL (dK/dV of a GQA group are summed in registers) */
     int deterministic;
     void *stream;                    /* hipStream_t */
     /* Optional instrumentation (NULL = off): array of 4 hipEvent_t that vfa_mha_bwd /
@@ -110,6 +111,15 @@ typedef struct vfa_params {
      * (flash_api.cpp:339-340,353).  For testing, like the reference's. */
     void *s_dmask;
     int seqlen_q_rounded, seqlen_k_rounded;
+    /* Backward head split (no counterpart in the reference, which has no backward kernel): with
+     * bwd_head_splits > 1 the query heads of a KV group are swept by that many workgroups per key
+     * block, which leave fp32 partial dK / dV in dk_accum / dv_accum -- each
+     * (bwd_head_splits, bwd_part_rows, h_k, d) contiguous, bwd_part_rows = b * seqlen_k for dense
+     * batches, total_k for ragged ones -- and a reduce kernel adds the slabs in index order (the
+     * result stays bitwise reproducible).  For launches with too few (batch, kv head, key block)
+     * items to fill the chip; vfa_bwd_head_splits() suggests the count.  0 / 1 = off. */
+    int bwd_head_splits;
+    int64_t bwd_part_rows;
 } vfa_params;
 
 /* Forward, dense batch.  Replaces mha_fwd, csrc/flash_attn/flash_api.cpp:240-420
@@ -145,6 +155,10 @@ int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, int max_seql
 /* Elements of the fp32 dq_accum buffer of the reference's parameter block
  * (csrc/flash_attn/src/flash.h:153-156); this library does not need the buffer. */
 size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_0);
+
+/* Head-split count the backward should use for these dims on a device with num_cus compute units
+ * (1 = none): see vfa_params.bwd_head_splits. */
+int vfa_bwd_head_splits(int batch, int num_heads, int num_heads_k, int max_seqlen_k, int num_cus);
 
 /* sizeof(vfa_params) of the built library, for foreign-function bindings to check their mirror of
  * the struct against (no counterpart in the reference: its boundary is typed by pybind). */

@@ -42,6 +42,7 @@ class VfaParams(C.Structure):
         ("stage_events", _p),
         ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64), ("rng_state", _p),
         ("s_dmask", _p), ("seqlen_q_rounded", _int), ("seqlen_k_rounded", _int),
+        ("bwd_head_splits", _int), ("bwd_part_rows", _i64),
     ]
 
 
@@ -67,6 +68,7 @@ def lib():
         _lib.vfa_splitkv_num_splits.argtypes = [_int] * 6
         _lib.vfa_bwd_dq_accum_elems.argtypes = [_int] * 5
         _lib.vfa_bwd_dq_accum_elems.restype = C.c_size_t
+        _lib.vfa_bwd_head_splits.argtypes = [_int] * 5
         assert _lib.vfa_params_sizeof() == C.sizeof(VfaParams), "ctypes mirror of vfa_params is stale"
     return _lib
 
@@ -188,7 +190,7 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
 def bwd(dout, q, k, v, out, lse, *, softmax_scale=None, causal=False, window=(-1, -1),
         alibi_slopes=None, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=None,
         max_seqlen_k=None, deterministic=False, p_dropout=0.0, philox_seed=0, philox_offset=0,
-        rng_state=None):
+        rng_state=None, head_splits=None):
     """Backward through the C ABI.  Returns (dq, dk, dv, softmax_d)."""
     import torch
     P = VfaParams()
@@ -223,5 +225,14 @@ def bwd(dout, q, k, v, out, lse, *, softmax_scale=None, causal=False, window=(-1
     P.p_dropout, P.philox_seed, P.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)
     if rng_state is not None:
         P.rng_state = rng_state.data_ptr()
+    if head_splits is None:  # what the torch extension does: ask the library
+        cus = torch.cuda.get_device_properties(q.device).multi_processor_count
+        head_splits = lib().vfa_bwd_head_splits(b, h, hk, sk, cus)
+    if head_splits > 1:
+        rows = k.shape[0] if varlen else b * sk
+        dka = torch.empty(head_splits, rows, hk, d, dtype=torch.float32, device=q.device)
+        dva = torch.empty_like(dka)
+        P.bwd_head_splits, P.bwd_part_rows = head_splits, rows
+        P.dk_accum, P.dv_accum = dka.data_ptr(), dva.data_ptr()
     call("vfa_mha_varlen_bwd" if varlen else "vfa_mha_bwd", P)
     return dq, dk, dv, sd

@@ -239,3 +239,44 @@ def test_block_order_covers_every_block(b, h, hk, sq, sk, d, causal):
         assert torch.equal(o1, out[s_]) and torch.equal(l1, lse[s_])
         g1 = cabi.bwd(do[s_], q[s_], k[s_], v[s_], o1, l1, causal=causal)
         assert torch.equal(g1[0], dq[s_]) and torch.equal(g1[1], dk[s_]) and torch.equal(g1[2], dv[s_])
+
+
+@pytest.mark.parametrize("b,h,hk,sq,sk,d,varlen", [(1, 8, 1, 300, 520, 128, False), (2, 6, 2, 257, 257, 64, False),
+                                                  (1, 4, 2, 100, 700, 128, True), (1, 16, 4, 1030, 1030, 128, False)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_bwd_head_split_matches_unsplit_and_oracle(b, h, hk, sq, sk, d, varlen, causal):
+    """Few (batch, kv head) pairs: the heads of a KV group are swept by several workgroups per key
+    block and their fp32 partial dK / dV are added by the reduce kernel.  Every split count, also
+    the one the library suggests, against the unsplit call (dq bitwise, dk / dv to one rounding of
+    the 16-bit result) and the oracle; twice, bitwise equal (slabs are added in index order)."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(h * 10 + hk)
+    g = h // hk
+    if varlen:
+        ql, kl = [sq, sq // 2 + 1], [sk, sk // 3 + 2]
+        q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.bfloat16)
+        k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.bfloat16)
+        kw = dict(causal=causal, cu_seqlens_q=_cu(ql), cu_seqlens_k=_cu(kl), max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+        okw = dict(causal=causal, cu_seqlens_q=_cu(ql).cpu().numpy(), cu_seqlens_k=_cu(kl).cpu().numpy(),
+                   max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+    else:
+        q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+        k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+        kw, okw = dict(causal=causal), dict(causal=causal)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    out, lse = cabi.fwd(q, k, v, **kw)
+    dq1, dk1, dv1, _ = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)
+    o_dq, o_dk, o_dv, _ = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), f32(out), f32(lse), dtype="bf16", **okw)
+    for hs in sorted({2, g, None}, key=lambda x: (x is None, x)):
+        if hs is not None and hs > g:
+            continue
+        dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, head_splits=hs, **kw)
+        dq_, dk_, dv_, _ = cabi.bwd(do, q, k, v, out, lse, head_splits=hs, **kw)
+        assert torch.equal(dq, dq_) and torch.equal(dk, dk_) and torch.equal(dv, dv_)
+        assert torch.equal(dq, dq1)
+        for a, a1, o in ((dk, dk1, o_dk), (dv, dv1, o_dv)):
+            assert np.abs(f32(a) - f32(a1)).max() <= ulp_tol("bf16", o)
+            assert np.abs(f32(a) - o).max() <= 2 * ulp_tol("bf16", o)

@@ -303,6 +303,16 @@ extern "C" size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int 
     return rows * (size_t)h * (size_t)d;
 }
 
+extern "C" int vfa_bwd_head_splits(int batch, int num_heads, int num_heads_k, int max_seqlen_k, int num_cus_) {
+    // The dK/dV kernel's work items are (batch, kv head, 256-key block); aim at two per CU.
+    if (num_heads_k <= 0 || num_heads % num_heads_k != 0) return 1;
+    const int g = num_heads / num_heads_k;
+    const long long blocks = (long long)((max_seqlen_k + 255) / 256) * batch * num_heads_k;
+    const long long target = 2LL * num_cus_;
+    if (g == 1 || blocks <= 0 || blocks >= target) return 1;
+    return (int)std::min<long long>(g, (target + blocks - 1) / blocks);
+}
+
 static int bwd_common(const vfa_params *p, bool varlen) {
     g_err.clear();
     int rc = common_checks(p);
@@ -324,6 +334,15 @@ static int bwd_common(const vfa_params *p, bool varlen) {
     k.deterministic = p->deterministic;
     k.seqlen_q_rounded = (p->seqlen_q + 127) / 128 * 128;
     k.rng_read = p->rng_state != nullptr;
+    if (p->bwd_head_splits > 1) {
+        VFA_CHECK(p->dk_accum && p->dv_accum && p->bwd_part_rows > 0,
+                  "bwd_head_splits > 1 needs dk_accum / dv_accum slabs and bwd_part_rows");
+        VFA_CHECK(p->bwd_head_splits <= p->h / p->h_k, "bwd_head_splits exceeds the heads per KV head");
+        k.hsplit = p->bwd_head_splits;
+        k.dk_part = p->dk_accum; k.dv_part = p->dv_accum;
+        k.part_rows = p->bwd_part_rows;
+        k.part_stride = p->bwd_part_rows * p->h_k * p->d;
+    }
     hipError_t e = p->p_dropout > 0.f
                        ? vfa::run_bwd_dropout(k, (hipStream_t)p->stream, (hipEvent_t *)p->stage_events)
                        : vfa::run_bwd(k, (hipStream_t)p->stream, (hipEvent_t *)p->stage_events);

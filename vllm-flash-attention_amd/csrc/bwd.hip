@@ -226,7 +226,15 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const bool has_alibi = p.alibi_slopes != nullptr;
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
     const int n_steps_per_head = max(m_max - m_min, 0);
-    const int total_steps = n_steps_per_head * p.h_ratio;
+    // Head split (p.hsplit > 1, blockIdx.y): this workgroup sweeps only heads [h_lo, h_lo + nh) of
+    // the GQA group and leaves fp32 partial dK / dV in its slab of p.dk_part / p.dv_part for
+    // bwd_kv_reduce_kernel -- for launches with too few (batch, kv head, key block) items to fill
+    // the chip (small batch with MQA / GQA).
+    const int hsplit = p.hsplit > 1 ? p.hsplit : 1;
+    const int gper = (p.h_ratio + hsplit - 1) / hsplit;
+    const int h_lo = (int)blockIdx.y * gper;
+    const int nh = max(0, min(p.h_ratio, h_lo + gper) - h_lo);
+    const int total_steps = n_steps_per_head * nh;
 
     // ---- Q / dO slice staging (register prefetch, two LDS buffers) ----
     float rowc = 0.f;  // lse (tid < QM) or delta (QM <= tid < 2 QM) of the slice
@@ -242,7 +250,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // group, b4 s4096 d128 causal: see the dK/dV figures in the design notes).  Kept as counters (an
     // integer division per step costs more instructions than the step's address arithmetic).
     auto advance = [&](int &hh_, int &m_) {
-        if (++hh_ == p.h_ratio) {
+        if (++hh_ == nh) {
             hh_ = 0;
             --m_;
         }
@@ -278,7 +286,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     constexpr int NSTG = SPLIT ? 1 : QCH;  // staging register sets
     i32x4 qreg[NSTG], doreg[NSTG];
     auto load_chunk = [&](const int gh, const int m, const int i, const int slot) {
-        const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
+        const int bidh = hk * p.h_ratio + h_lo + gh, q0 = m * BW_QM;
         const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
         const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
         if constexpr (FAST) {
@@ -313,7 +321,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     auto load_slice_direct = [&](const int gh, const int m, const int buf) __attribute__((always_inline)) {
         if constexpr (DIRECT) {
             typedef __attribute__((address_space(3))) void *lds_ptr;
-            const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
+            const int bidh = hk * p.h_ratio + h_lo + gh, q0 = m * BW_QM;
             const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) + (int64_t)bidh * p.q_hs;
             const unsigned short *dog = (const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb) + (int64_t)bidh * p.do_hs;
             const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -332,7 +340,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }
     };
     auto load_rowc = [&](const int gh, const int m) {
-        const int bidh = hk * p.h_ratio + gh, q0 = m * BW_QM;
+        const int bidh = hk * p.h_ratio + h_lo + gh, q0 = m * BW_QM;
         if (tid < 2 * BW_QM) {
             const int row = q0 + (tid & (BW_QM - 1));
             const bool ok = row < sq;
@@ -409,7 +417,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
 #endif
     int buf = 0;
     for (int step = 0; step < total_steps; step++) {
-        const int bidh = hk * p.h_ratio + cur_h, q0s = cur_m * BW_QM;
+        const int bidh = hk * p.h_ratio + h_lo + cur_h, q0s = cur_m * BW_QM;
         const bool has_next = step + 1 < total_steps;
         STAMP(7);
         if (has_next) {
@@ -586,6 +594,29 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     }
 #endif
 
+    if (hsplit > 1) {
+        // fp32 partials straight from the accumulators: lane (r, hh) holds, per d block and group
+        // g4, four consecutive columns of key row kw0 + r.  Slab layout: (rows, h_k, d) contiguous,
+        // rows = (batch, key) dense or the packed key rows of a ragged batch.
+        if (kw0 + r < sk) {
+            const int64_t row = (bi.sum_s_k >= 0 ? (int64_t)bi.sum_s_k : (int64_t)bidb * p.seqlen_k) + kw0 + r;
+            const int64_t off = (int64_t)blockIdx.y * p.part_stride + (row * p.h_k + hk) * p.d;
+            const float rp = DROP ? p.rp_dropout : 1.f;
+#pragma unroll
+            for (int db = 0; db < NDB; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int col = 32 * db + 8 * g4 + 4 * hh;
+                    if (col < p.d) {
+                        *(f32x4 *)(p.dk_part + off + col) = f32x4{dk[db][4 * g4] * p.scale_rp, dk[db][4 * g4 + 1] * p.scale_rp,
+                                                                  dk[db][4 * g4 + 2] * p.scale_rp, dk[db][4 * g4 + 3] * p.scale_rp};
+                        *(f32x4 *)(p.dv_part + off + col) = f32x4{dv[db][4 * g4] * rp, dv[db][4 * g4 + 1] * rp,
+                                                                  dv[db][4 * g4 + 2] * rp, dv[db][4 * g4 + 3] * rp};
+                    }
+                }
+        }
+        return;
+    }
     // ---- write dK (scaled) and dV for this wave's 32 keys, through LDS as whole rows ----
     __syncthreads();
     char *ob = smem + wave * 32 * Cfg::OUT_ROWB;
@@ -623,6 +654,52 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     }
 }
 
+// Sum of the head-split partials -> dk, dv (16 bit), slabs added in index order (deterministic).
+// One thread per 8 consecutive d of one (key row, kv head).
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+bwd_kv_reduce_kernel(const KParams p, const int64_t n_rows) {
+    const int cpr = p.d / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = n_rows * p.h_k * cpr;
+    if (idx >= total) return;
+    const int ch = (int)(idx % cpr);
+    const int hk = (int)((idx / cpr) % p.h_k);
+    const int64_t row = idx / ((int64_t)cpr * p.h_k);
+    // row -> (batch, key): dense rows are batch-major; ragged rows are found in cu_seqlens_k
+    int bidb, key;
+    if (p.cu_seqlens_k) {
+        int lo = 0, hi = p.b;  // last b with cu[b] <= row
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (p.cu_seqlens_k[mid] <= row) lo = mid; else hi = mid;
+        }
+        bidb = lo;
+        key = (int)(row - p.cu_seqlens_k[lo]);
+    } else {
+        bidb = (int)(row / p.seqlen_k);
+        key = (int)(row % p.seqlen_k);
+    }
+    const BlockInfo bi(p, bidb);
+    const int64_t off = (row * p.h_k + hk) * p.d + ch * 8;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        const float *src = (which == 0 ? p.dk_part : p.dv_part) + off;
+        f32x4 a0 = *(const f32x4 *)src, a1 = *(const f32x4 *)(src + 4);
+        for (int s = 1; s < p.hsplit; s++) {
+            a0 += *(const f32x4 *)(src + (int64_t)s * p.part_stride);
+            a1 += *(const f32x4 *)(src + (int64_t)s * p.part_stride + 4);
+        }
+        i32x4 w;
+        w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
+        w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
+        unsigned short *dst = which == 0
+            ? (unsigned short *)p.dk + bi.k_off(p.dk_bs, p.dk_rs, bidb) + (int64_t)key * p.dk_rs + (int64_t)hk * p.dk_hs
+            : (unsigned short *)p.dv + bi.k_off(p.dv_bs, p.dv_rs, bidb) + (int64_t)key * p.dv_rs + (int64_t)hk * p.dv_hs;
+        *(i32x4 *)(dst + ch * 8) = w;
+    }
+}
+
 // Per-(batch) extents that fit a 32-bit byte offset (with room for the tile offsets) take the
 // buffer-load paths of the kernels below.
 static bool bwd_fits_buffer(const KParams &p) {
@@ -643,7 +720,8 @@ static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), LDS, stream, p, n_kblocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.hsplit > 1 ? p.hsplit : 1)), dim3(Cfg::NT), LDS,
+                       stream, p, n_kblocks);
     return hipGetLastError();
 }
 
@@ -999,6 +1077,11 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     if (e != hipSuccess) return e;
+    if (p.hsplit > 1) {
+        const int64_t items = p.part_rows * p.h_k * (p.d / 8);
+        hipLaunchKernelGGL(bwd_kv_reduce_kernel<BF16>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p,
+                           p.part_rows);
+    }
     if (ev) (void)hipEventRecord(ev[2], stream);
     {
         // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU: measured

@@ -606,7 +606,15 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
     auto opts = q.options();
     const int64_t sq_rounded = (sq + 127) / 128 * 128;
     Tensor softmax_d = torch::empty({b, h, sq_rounded}, opts.dtype(at::kFloat));
-    // (no fp32 dq / dk / dv accumulators: the kernels accumulate in registers, flash.h:153-156)
+    // No fp32 dq accumulator (the kernels accumulate in registers, flash.h:153-156); fp32 dK / dV
+    // slabs only when the heads of a KV group are split over workgroups to fill the chip.
+    const int head_splits = vfa_bwd_head_splits((int)b, (int)h, (int)hk, (int)sk, cu_count());
+    const int64_t part_rows = varlen ? total_k : b * sk;
+    Tensor dk_accum, dv_accum;
+    if (head_splits > 1) {
+        dk_accum = torch::empty({head_splits, part_rows, hk, d}, opts.dtype(at::kFloat));
+        dv_accum = torch::empty({head_splits, part_rows, hk, d}, opts.dtype(at::kFloat));
+    }
     if (zero_tensors) { dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_(); }
 
     vfa_params P{};
@@ -634,6 +642,12 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
     P.dsoftmax_sum = softmax_d.data_ptr<float>();
     P.deterministic = deterministic;
     P.stream = current_stream();
+    if (head_splits > 1) {
+        P.bwd_head_splits = head_splits;
+        P.bwd_part_rows = part_rows;
+        P.dk_accum = dk_accum.data_ptr<float>();
+        P.dv_accum = dv_accum.data_ptr<float>();
+    }
     // The forward's Philox state: the rng_state tensor it returned (read on the device), else a
     // fresh draw from the generator like the upstream backward does when none is passed.
     P.p_dropout = (float)p_dropout;

@@ -58,6 +58,10 @@ struct KParams {
     int rng_read;                // backward: take seed / offset from rng_state
     void *s_dmask;               // (b, h, sq_rounded_p, sk_rounded_p) 16-bit or null
     int sq_rounded_p, sk_rounded_p;
+    // backward head split: fp32 partial dK / dV slabs (hsplit, part_rows, h_k, d)
+    int hsplit;
+    float *dk_part, *dv_part;
+    int64_t part_stride, part_rows;
 };
 
 // Per-batch lengths and offsets: csrc/flash_attn/src/block_info.h:15-34.
