@@ -346,7 +346,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const bool ok = row < sq;
             if (tid < BW_QM) {
                 const float l = ok ? p.lse[((int64_t)bidb * p.h + bidh) * p.seqlen_q + row] : INFINITY;
-                rowc = LSE_IN_ACC ? -l / p.scale : l;
+                rowc = l;  // (turned into -LSE / scale when it is stored: touching it here would
+                           //  make this wave wait for the load it has just issued)
             }
             else rowc = ok ? p.dsoftmax_sum[((int64_t)bidb * p.h + bidh) * p.seqlen_q_rounded + row] : 0.f;
         }
@@ -378,7 +379,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     };
     auto store_rowc = [&](int buf) {
         char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
-        if (tid < 2 * BW_QM) ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = rowc;
+        if (tid < 2 * BW_QM)
+            ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = (LSE_IN_ACC && tid < BW_QM) ? -rowc / p.scale : rowc;
     };
     auto store_slice = [&](int buf) {
         if constexpr (!SPLIT) {
