@@ -118,7 +118,7 @@ struct BwdCfg {
     static constexpr int QCH = (QM * CPR + NT - 1) / NT;      // chunks per thread per Q (or dO) slice
 };
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS>
 __global__ void __launch_bounds__(NW * 64, 1)
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
@@ -226,14 +226,14 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const bool has_alibi = p.alibi_slopes != nullptr;
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
     const int n_steps_per_head = max(m_max - m_min, 0);
-    // Head split (p.hsplit > 1, blockIdx.y): this workgroup sweeps only heads [h_lo, h_lo + nh) of
-    // the GQA group and leaves fp32 partial dK / dV in its slab of p.dk_part / p.dv_part for
+    // Head split (HS: p.hsplit > 1, blockIdx.y): this workgroup sweeps only heads [h_lo, h_lo + nh)
+    // of the GQA group and leaves fp32 partial dK / dV in its slab of p.dk_part / p.dv_part for
     // bwd_kv_reduce_kernel -- for launches with too few (batch, kv head, key block) items to fill
-    // the chip (small batch with MQA / GQA).
-    const int hsplit = p.hsplit > 1 ? p.hsplit : 1;
-    const int gper = (p.h_ratio + hsplit - 1) / hsplit;
-    const int h_lo = (int)blockIdx.y * gper;
-    const int nh = max(0, min(p.h_ratio, h_lo + gper) - h_lo);
+    // the chip (small batch with MQA / GQA).  A template parameter: as a run-time branch its
+    // scalars cost the unsplit kernel 5 more spilled SGPRs and 8 % of its time.
+    const int gper = HS ? (p.h_ratio + p.hsplit - 1) / p.hsplit : p.h_ratio;
+    const int h_lo = HS ? (int)blockIdx.y * gper : 0;
+    const int nh = HS ? max(0, min(p.h_ratio, h_lo + gper) - h_lo) : p.h_ratio;
     const int total_steps = n_steps_per_head * nh;
 
     // ---- Q / dO slice staging (register prefetch, two LDS buffers) ----
@@ -596,7 +596,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     }
 #endif
 
-    if (hsplit > 1) {
+    if constexpr (HS) {
         // fp32 partials straight from the accumulators: lane (r, hh) holds, per d block and group
         // g4, four consecutive columns of key row kw0 + r.  Slab layout: (rows, h_k, d) contiguous,
         // rows = (batch, key) dense or the packed key rows of a ragged batch.
@@ -618,7 +618,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                 }
         }
         return;
-    }
+    } else {
     // ---- write dK (scaled) and dV for this wave's 32 keys, through LDS as whole rows ----
     __syncthreads();
     char *ob = smem + wave * 32 * Cfg::OUT_ROWB;
@@ -654,6 +654,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }
         __syncthreads();
     }
+    }  // !HS
 }
 
 // Sum of the head-split partials -> dk, dv (16 bit), slabs added in index order (deterministic).
@@ -710,21 +711,27 @@ static bool bwd_fits_buffer(const KParams &p) {
     return rq * p.q_rs * 2 < lim && rq * p.do_rs * 2 < lim && rk * p.k_rs * 2 < lim && rk * p.v_rs * 2 < lim;
 }
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
-static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS>
+static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
     using Cfg = BwdCfg<DP, NW>;
     constexpr int LDS = Cfg::LDS_BYTES + (DROP ? NW * 1024 : 0);  // + the Philox exchange space
     const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP>;
+    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS>;
     if (LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.hsplit > 1 ? p.hsplit : 1)), dim3(Cfg::NT), LDS,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(HS ? p.hsplit : 1)), dim3(Cfg::NT), LDS,
                        stream, p, n_kblocks);
     return hipGetLastError();
+}
+
+template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
+static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
+    return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true>(p, stream)
+                        : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false>(p, stream);
 }
 
 template <int DP, bool BF16, int NW, bool DROP>
