@@ -477,6 +477,39 @@ def test_kvcache_without_seqlens_and_seqlen_k_zero():
     assert torch.equal(o0, torch.zeros_like(o0)) and torch.isposinf(l0).all()
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_paged_kvcache_append_into_large_pool(causal):
+    """The shapes of tests/test_flash_attn.py:2466-2507 (170 new tokens appended to an empty paged
+    cache, 1000 pages of 16 rows, 32 heads, d 128), run 10 times like the reference.  There the
+    page table is drawn with repetitions and the test only has to survive; here every other round
+    draws distinct pages, so that the result can be checked: with empty caches the output is the
+    attention of q over the new k / v alone, and the pages hold exactly the new rows."""
+    import vllm_flash_attn as fa
+    torch.manual_seed(21)
+    b, sq, h, d, page, nblk = 4, 170, 32, 128, 16, 1000
+    kc = torch.rand(nblk, page, h, d, device="cuda", dtype=torch.float16)
+    vc = torch.rand_like(kc)
+    lens = torch.zeros(b, dtype=torch.int32, device="cuda")
+    per = (sq + page - 1) // page
+    for it in range(10):
+        q = torch.rand(b, sq, h, d, device="cuda", dtype=torch.float16)
+        k = torch.rand_like(q)
+        v = torch.rand_like(q)
+        if it % 2:
+            bt = torch.randint(0, nblk, (b, per), dtype=torch.int32, device="cuda")
+        else:
+            bt = torch.randperm(nblk, device="cuda")[:b * per].to(torch.int32).view(b, per)
+        out = fa.flash_attn_with_kvcache(q, kc, vc, k=k, v=v, cache_seqlens=lens, block_table=bt, causal=causal)
+        assert torch.isfinite(out).all()
+        if it % 2:
+            continue
+        ref = fa.flash_attn_func(q, k, v, causal=causal)
+        assert (out.float() - ref.float()).abs().max().item() <= 2 * 2.0 ** -11
+        got_k = kc[bt.long()].reshape(b, per * page, h, d)[:, :sq]
+        got_v = vc[bt.long()].reshape(b, per * page, h, d)[:, :sq]
+        assert torch.equal(got_k, k) and torch.equal(got_v, v)
+
+
 def test_kvcache_gqa_decode_writes_caller_shaped_out():
     """seqlen_q = 1 with grouped heads takes the (b, ngroups, h_k, d) fold; an `out` of the caller's
     own shape (b, 1, h, d) is filled in place.  (The reference checks `out` against the folded shape
