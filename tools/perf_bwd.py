@@ -17,7 +17,8 @@ def main():
     torch.manual_seed(0)
     shapes = [(8, 4096, 32, 32, 128, True, "bf16"), (8, 4096, 32, 32, 128, False, "bf16"),
               (4, 2048, 16, 16, 64, True, "bf16"), (4, 4096, 32, 8, 128, True, "bf16"),
-              (2, 8192, 16, 16, 128, True, "bf16"), (16, 1024, 16, 16, 128, True, "bf16")]
+              (2, 8192, 16, 16, 128, True, "bf16"), (16, 1024, 16, 16, 128, True, "bf16"),
+              (32, 512, 16, 16, 128, True, "bf16"), (32, 512, 16, 16, 128, False, "bf16")]
     if len(sys.argv) > 1:
         shapes = [shapes[int(a)] for a in sys.argv[1:]]
     stream = torch.cuda.current_stream().cuda_stream
