@@ -120,6 +120,12 @@ typedef struct vfa_params {
      * items to fill the chip; vfa_bwd_head_splits() suggests the count.  0 / 1 = off. */
     int bwd_head_splits;
     int64_t bwd_part_rows;
+    /* Rows of rotary_cos / rotary_sin (flash_api.cpp:876-877: must be >= seqlen_k).  A query row is
+     * rotated at position cache_seqlen (+ its row index under a causal or window mask), which a
+     * caller can push past seqlen_k by appending fewer new keys than it has query rows; with
+     * seqlen_ro > 0 that position is clamped to the table's last row instead of being read past
+     * its end.  0 = unknown: no clamp and no check (the reference kernel's behaviour). */
+    int seqlen_ro;
 } vfa_params;
 
 /* Forward, dense batch.  Replaces mha_fwd, csrc/flash_attn/flash_api.cpp:240-420

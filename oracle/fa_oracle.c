@@ -305,6 +305,7 @@ static void tile_pass(const fa_oracle_params *p, const mask_cfg *mc, const block
         float qrot[MAXD];
         if (p->knew && p->rotary_dim > 0) { /* flash_fwd_kernel.h:785-824 */
             int pos = bi->seqlen_k_cache + ((mc->is_causal || mc->is_local) ? row_idx : 0);
+            if (p->seqlen_ro > 0 && pos > p->seqlen_ro - 1) pos = p->seqlen_ro - 1;
             rotary_row(p, qr, qrot, pos);
             qr = qrot;
         }

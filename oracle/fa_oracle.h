@@ -73,6 +73,11 @@ typedef struct fa_oracle_params {
      * Only entries of visited tiles with row < seqlen_q and col < seqlen_k are written. */
     float *s_dmask;
     int seqlen_q_rounded, seqlen_k_rounded;
+    /* rows of rotary_cos / rotary_sin (flash_api.cpp:876-877); > 0: the query's rotary position is
+     * clamped to the last row (the reference kernel reads past the table when a caller appends
+     * fewer keys than it has query rows under a causal mask; its own tests avoid that case,
+     * tests/test_flash_attn.py:1955-1964) */
+    int seqlen_ro;
 } fa_oracle_params;
 
 /* flash_api.cpp:289-294,121-124: window clamp, causal fold, one-sided fill. */

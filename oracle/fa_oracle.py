@@ -38,6 +38,7 @@ class _Params(C.Structure):
         ("is_rotary_interleaved", C.c_int),
         ("p_dropout", C.c_float), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
         ("s_dmask", C.c_void_p), ("seqlen_q_rounded", C.c_int), ("seqlen_k_rounded", C.c_int),
+        ("seqlen_ro", C.c_int),
     ]
 
 
@@ -192,6 +193,7 @@ def attention_fwd(q, k, v, *, dtype="fp32", softmax_scale=None, causal=False, wi
             keep += [rc, rs]
             p.rotary_cos, p.rotary_sin = _ptr(rc), _ptr(rs)
             p.rotary_dim = rc.shape[1] * 2
+            p.seqlen_ro = rc.shape[0]
             p.is_rotary_interleaved = int(rotary_interleaved)
     p.p_dropout, p.philox_seed, p.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)
     sdm = None

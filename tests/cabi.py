@@ -42,7 +42,7 @@ class VfaParams(C.Structure):
         ("stage_events", _p),
         ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64), ("rng_state", _p),
         ("s_dmask", _p), ("seqlen_q_rounded", _int), ("seqlen_k_rounded", _int),
-        ("bwd_head_splits", _int), ("bwd_part_rows", _i64),
+        ("bwd_head_splits", _int), ("bwd_part_rows", _i64), ("seqlen_ro", _int),
     ]
 
 
@@ -168,6 +168,7 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
         if rotary_cos is not None:
             P.rotary_cos, P.rotary_sin = rotary_cos.data_ptr(), rotary_sin.data_ptr()
             P.rotary_dim = rotary_cos.shape[1] * 2
+            P.seqlen_ro = rotary_cos.shape[0]
             P.is_rotary_interleaved = int(rotary_interleaved)
     P.stream = _stream()
     P.p_dropout, P.philox_seed, P.philox_offset = float(p_dropout), int(philox_seed), int(philox_offset)

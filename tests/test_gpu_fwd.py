@@ -510,6 +510,43 @@ def test_paged_kvcache_append_into_large_pool(causal):
         assert torch.equal(got_k, k) and torch.equal(got_v, v)
 
 
+def test_kvcache_rotary_position_past_the_table_is_clamped():
+    """More query rows than appended keys under a causal mask: the query's rotary position
+    cache_seqlen + row runs past seqlen_k, where a cos / sin table of exactly seqlen_k rows ends
+    (the reference kernel reads past it; its tests keep cache_seqlens low enough,
+    tests/test_flash_attn.py:1955-1964).  Here the position stops at the table's last row, in the
+    kernel and in the oracle alike, and the result does not depend on what follows the table."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(8)
+    b, sq, sk, h, hk, d, rd = 2, 64, 128, 4, 2, 128, 64
+    dt = torch.float16
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=dt)
+    knew = torch.randn(b, 1, hk, d, device="cuda", dtype=dt)
+    vnew = torch.randn_like(knew)
+    cs = torch.tensor([127, 100], dtype=torch.int32, device="cuda")
+    big = torch.rand(sk + 64, rd // 2, device="cuda") * 6.28
+    outs = []
+    for fill in (0.0, float("nan")):
+        store_c, store_s = torch.cos(big).to(dt), torch.sin(big).to(dt)
+        store_c[sk:] = fill   # what lies behind the table must not matter
+        store_s[sk:] = fill
+        cos, sin = store_c[:sk], store_s[:sk]
+        kc = torch.randn(b, sk, hk, d, device="cuda", dtype=dt, generator=torch.Generator("cuda").manual_seed(1))
+        vc = torch.randn(b, sk, hk, d, device="cuda", dtype=dt, generator=torch.Generator("cuda").manual_seed(2))
+        np_ = lambda t: t.float().cpu().numpy() if t.is_floating_point() else t.cpu().numpy()
+        ro = fa_oracle.attention_fwd(np_(q), np_(kc), np_(vc), dtype="fp16", causal=True, cache_seqlens=np_(cs),
+                                     knew=np_(knew), vnew=np_(vnew), rotary_cos=np_(cos), rotary_sin=np_(sin),
+                                     rotary_interleaved=False)[0]
+        out = fa.flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                         cache_seqlens=cs, causal=True, rotary_interleaved=False)
+        assert torch.isfinite(out).all()
+        assert np.abs(np_(out) - ro).max() <= 4 * ulp_tol("fp16", ro)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_kvcache_gqa_decode_writes_caller_shaped_out():
     """seqlen_q = 1 with grouped heads takes the (b, ngroups, h_k, d) fold; an `out` of the caller's
     own shape (b, 1, h, d) is filled in place.  (The reference checks `out` against the folded shape

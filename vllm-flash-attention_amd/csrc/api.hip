@@ -292,6 +292,8 @@ extern "C" int vfa_mha_fwd_kvcache(const vfa_params *p) {
         VFA_CHECK(p->rotary_dim % 16 == 0, "Only rotary dimensions divisible by 16 are currently supported");
         k.rotary_cos = p->rotary_cos; k.rotary_sin = p->rotary_sin;
         k.rotary_dim = p->rotary_dim; k.rotary_interleaved = p->is_rotary_interleaved;
+        VFA_CHECK(p->seqlen_ro == 0 || p->seqlen_ro >= p->seqlen_k, "cos/sin seqlen must be at least the seqlen of KV cache");
+        k.seqlen_ro = p->seqlen_ro;
     }
     // flash_api.cpp:919: appending, cache_batch_idx and paged caches take the split kernel
     const bool force = p->knew || p->cache_batch_idx || p->block_table;

@@ -209,7 +209,8 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         if (p.knew && p.rotary_dim > 0 && rok) {
             // flash_fwd_kernel.h:785-824: the query is rotated with position seqlen_k_cache
             // (+ its row index when causal or local)
-            const int pos = bi.sk_cache + ((p.is_causal || p.is_local) ? row : 0);
+            int pos = bi.sk_cache + ((p.is_causal || p.is_local) ? row : 0);
+            if (p.seqlen_ro > 0) pos = min(pos, p.seqlen_ro - 1);  // never past the table's end
             const int half = p.rotary_dim / 2;
             const unsigned short *cosp = (const unsigned short *)p.rotary_cos + (int64_t)pos * half;
             const unsigned short *sinp = (const unsigned short *)p.rotary_sin + (int64_t)pos * half;

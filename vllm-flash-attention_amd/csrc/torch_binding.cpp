@@ -514,6 +514,7 @@ std::vector<Tensor> fwd_kvcache(Tensor &q, const Tensor &kcache, const Tensor &v
         TORCH_CHECK(rs.scalar_type() == q.scalar_type(), "rotary_cos must have the same dtype as query");
         P.rotary_cos = rc.data_ptr(); P.rotary_sin = rs.data_ptr();
         P.is_rotary_interleaved = is_rotary_interleaved;
+        P.seqlen_ro = (int)s_ro;
     }
     if (cache_batch_idx_.has_value()) {
         const Tensor &c = cache_batch_idx_.value();

@@ -38,7 +38,7 @@ struct KParams {
     int64_t knew_bs, knew_rs, knew_hs, vnew_bs, vnew_rs, vnew_hs;
     int seqlen_knew;
     const void *rotary_cos, *rotary_sin;
-    int rotary_dim, rotary_interleaved;
+    int rotary_dim, rotary_interleaved, seqlen_ro;
     // backward
     const void *dout;
     void *dq, *dk, *dv;
