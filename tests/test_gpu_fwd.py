@@ -510,6 +510,42 @@ def test_paged_kvcache_append_into_large_pool(causal):
         assert torch.equal(got_k, k) and torch.equal(got_v, v)
 
 
+@pytest.mark.parametrize("num_splits", [0, 1, 3])
+@pytest.mark.parametrize("paged", [False, True])
+def test_kvcache_rotary_with_many_query_rows(num_splits, paged):
+    """130 query rows with appended keys and rotary tables, unsplit and split: the split variants
+    of the prefill kernel do not rotate the query, so these calls must stay on the kernel that
+    does (a forced split count used to take them and return unrotated-query results)."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(12)
+    b, sq, sk, h, hk, d, rd, page = 2, 130, 512, 8, 2, 128, 64, 32
+    dt = torch.bfloat16
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=dt)
+    knew = torch.randn(b, sq, hk, d, device="cuda", dtype=dt)
+    vnew = torch.randn_like(knew)
+    cs = torch.tensor([300, 7], dtype=torch.int32, device="cuda")
+    ang = torch.rand(sk, rd // 2, device="cuda") * 6.28
+    cos, sin = torch.cos(ang).to(dt), torch.sin(ang).to(dt)
+    if paged:
+        nb = b * (sk // page) + 2
+        kc = torch.randn(nb, page, hk, d, device="cuda", dtype=dt)
+        vc = torch.randn_like(kc)
+        bt = torch.randperm(nb)[: b * (sk // page)].reshape(b, -1).to(torch.int32).cuda()
+    else:
+        kc = torch.randn(b, sk, hk, d, device="cuda", dtype=dt)
+        vc = torch.randn_like(kc)
+        bt = None
+    np_ = lambda t: None if t is None else (t.float().cpu().numpy() if t.is_floating_point() else t.cpu().numpy())
+    ro = fa_oracle.attention_fwd(np_(q), np_(kc), np_(vc), dtype="bf16", causal=True, cache_seqlens=np_(cs),
+                                 block_table=np_(bt), knew=np_(knew), vnew=np_(vnew), rotary_cos=np_(cos),
+                                 rotary_sin=np_(sin), rotary_interleaved=True)[0]
+    out = fa.flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin, cache_seqlens=cs,
+                                     block_table=bt, causal=True, rotary_interleaved=True, num_splits=num_splits)
+    assert np.abs(np_(out) - ro).max() <= 4 * ulp_tol("bf16", ro)
+
+
 def test_kvcache_rotary_position_past_the_table_is_clamped():
     """More query rows than appended keys under a causal mask: the query's rotary position
     cache_seqlen + row runs past seqlen_k, where a cos / sin table of exactly seqlen_k rows ends

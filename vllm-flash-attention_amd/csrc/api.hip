@@ -212,8 +212,10 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
         k.oaccum = p->oaccum;
         k.lseaccum = p->softmax_lseaccum;
         // Few query rows: the decode kernel (waves split the keys of a 32-row block).  More: the
-        // prefill kernel's split variants (128-row blocks), when they can load this K/V layout.
-        if (k.seqlen_q > 64 && vfa::fwd_prefill_split_ok(k)) {
+        // prefill kernel's split variants (128-row blocks), when they can load this K/V layout
+        // (they do not rotate the query: rotary tables keep the decode kernel).
+        const bool q_rotary = k.knew && k.rotary_dim > 0;
+        if (k.seqlen_q > 64 && !q_rotary && vfa::fwd_prefill_split_ok(k)) {
             e = vfa::run_fwd_prefill_split(k, stream);
             if (e == hipSuccess) e = vfa::run_fwd_combine(k, stream);
         } else {
