@@ -317,3 +317,51 @@ def test_headline_shape_bwd_slices_and_linearity():
     for a, c in zip(g1, g2):
         assert torch.isfinite(a.float()).all()
         assert torch.equal(a * 2, c)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_every_packed_entry_point_matches_the_unpacked_one(causal):
+    """flash_attn_{qkvpacked,kvpacked,varlen_qkvpacked,varlen_kvpacked}_func, forward and autograd
+    backward, against flash_attn_func / flash_attn_varlen_func on the same data: the packed
+    arguments are strided views of the same elements, so outputs and gradients must be bit-equal
+    (the packed gradients come back stacked in the packed layout)."""
+    import vllm_flash_attn as fa
+    torch.manual_seed(17)
+    b, s, h, d = 3, 150, 4, 64
+    dt = torch.bfloat16
+    qkv = torch.randn(b, s, 3, h, d, device="cuda", dtype=dt)
+    g = torch.randn(b, s, h, d, device="cuda", dtype=dt)
+    q, k, v = (qkv[:, :, i].detach().clone().requires_grad_() for i in range(3))
+    ref = fa.flash_attn_func(q, k, v, causal=causal)
+    ref.backward(g)
+    p1 = qkv.detach().clone().requires_grad_()
+    o1 = fa.flash_attn_qkvpacked_func(p1, causal=causal)
+    o1.backward(g)
+    assert torch.equal(o1, ref)
+    assert torch.equal(p1.grad, torch.stack([q.grad, k.grad, v.grad], dim=2))
+    q2 = qkv[:, :, 0].detach().clone().requires_grad_()
+    kv2 = qkv[:, :, 1:].detach().clone().requires_grad_()
+    o2 = fa.flash_attn_kvpacked_func(q2, kv2, causal=causal)
+    o2.backward(g)
+    assert torch.equal(o2, ref) and torch.equal(q2.grad, q.grad)
+    assert torch.equal(kv2.grad, torch.stack([k.grad, v.grad], dim=2))
+    # ragged: three sequences packed back to back
+    lens = [150, 77, 1]
+    cu = torch.tensor([0, 150, 227, 228], dtype=torch.int32, device="cuda")
+    tot = sum(lens)
+    pk = torch.randn(tot, 3, h, d, device="cuda", dtype=dt)
+    gv = torch.randn(tot, h, d, device="cuda", dtype=dt)
+    qv, kv_, vv = (pk[:, i].detach().clone().requires_grad_() for i in range(3))
+    rv = fa.flash_attn_varlen_func(qv, kv_, vv, cu, cu, max(lens), max(lens), causal=causal)
+    rv.backward(gv)
+    p3 = pk.detach().clone().requires_grad_()
+    o3 = fa.flash_attn_varlen_qkvpacked_func(p3, cu, max(lens), causal=causal)
+    o3.backward(gv)
+    assert torch.equal(o3, rv)
+    assert torch.equal(p3.grad, torch.stack([qv.grad, kv_.grad, vv.grad], dim=1))
+    q4 = pk[:, 0].detach().clone().requires_grad_()
+    kv4 = pk[:, 1:].detach().clone().requires_grad_()
+    o4 = fa.flash_attn_varlen_kvpacked_func(q4, kv4, cu, cu, max(lens), max(lens), causal=causal)
+    o4.backward(gv)
+    assert torch.equal(o4, rv) and torch.equal(q4.grad, qv.grad)
+    assert torch.equal(kv4.grad, torch.stack([kv_.grad, vv.grad], dim=1))
