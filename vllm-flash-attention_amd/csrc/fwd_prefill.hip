@@ -757,7 +757,13 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     // is faster with 8 waves everywhere measured (+3..9 %); d = 128 causal / windowed crosses over
     // between seqlen 2048 (equal) and 4096 (+3 % for 8 waves; +5 % at 16k).
     const bool masked = p.is_causal || p.is_local;
-    const bool big = masked ? p.seqlen_q >= 4096 : p.seqlen_q >= 512;
+    // Under a window the keys a row block sees are the window's span, not the sequence: 4 waves
+    // are faster up to a span of 2048 (b2 s8192 h16, left window 256 / 1024 / 2048: -14 / -7 / -7 %
+    // time) and equal from 3072.
+    int64_t span = p.seqlen_k;
+    if (p.is_local)
+        span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
+    const bool big = masked ? (p.seqlen_q >= 4096 && span >= 3072) : p.seqlen_q >= 512;
     if (p.d <= 64) {
         return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
     } else if (p.d <= 128) {
