@@ -26,4 +26,17 @@ for wl in [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 1536, 2048, 3072, 4
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 8)
     ts.sort()
-    print(f"window {wl:5d}: {ts[3] * 1000:8.1f} us")
+    lse = cabi.fwd(q, k, v, causal=True, window=(wl, 0), out=out)[1]
+    do = torch.randn_like(q)
+    for _ in range(2):
+        cabi.bwd(do, q, k, v, out, lse, causal=True, window=(wl, 0))
+    tb = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            cabi.bwd(do, q, k, v, out, lse, causal=True, window=(wl, 0))
+        e1.record(); torch.cuda.synchronize()
+        tb.append(e0.elapsed_time(e1) / 4)
+    tb.sort()
+    print(f"window {wl:5d}: fwd {ts[3] * 1000:8.1f} us   bwd {tb[3] * 1000:8.1f} us")

@@ -1098,8 +1098,14 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         // mask up to seqlen 4096 (by up to 7 %) and without a mask below 2048; at d = 128, 8 waves
         // are equal or better (1..4 %) from seqlen 512 without a mask and from 1024 with one.
         const bool masked = p.is_causal || p.is_local;
-        const bool big = DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
-                                  : (masked ? p.seqlen_q >= 1024 : p.seqlen_q >= 512);
+        // Under a window a row block sees the window's span of keys, not the sequence: below 3072
+        // keys two 4-wave workgroups per CU win (b2 s8192 h16 d128, left window 256 / 1024 / 2048:
+        // backward -7 / -4 / -3 % time), from there 8 waves.
+        int64_t span = p.seqlen_k;
+        if (p.is_local)
+            span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
+        const bool big = (DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
+                                   : (masked ? p.seqlen_q >= 1024 : p.seqlen_q >= 512)) && span >= 3072;
         if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
         else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
