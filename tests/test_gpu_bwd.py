@@ -365,3 +365,31 @@ def test_every_packed_entry_point_matches_the_unpacked_one(causal):
     o4.backward(gv)
     assert torch.equal(o4, rv) and torch.equal(q4.grad, qv.grad)
     assert torch.equal(kv4.grad, torch.stack([kv_.grad, vv.grad], dim=1))
+
+
+@pytest.mark.parametrize("window,causal,alibi", [((3100, 0), True, False), ((3500, 40), False, True),
+                                                 ((1000, 0), True, True)])
+def test_long_sequence_window_paths_vs_oracle(window, causal, alibi):
+    """4200 rows under a sliding window, forward and backward against the oracle: windows that span
+    3072 keys or more keep the 8-wave forward / dQ workgroups (their window-edge masks and tile
+    skipping), shorter ones take the 4-wave ones on the same long sequence."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(5)
+    b, s, h, hk, d = 1, 4200, 2, 1, 128
+    q = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, s, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    slopes = (torch.rand(b, h, device="cuda") * 0.3) if alibi else None
+    kw = dict(causal=causal, window=window, alibi_slopes=slopes)
+    okw = dict(dtype="bf16", causal=causal, window=window, alibi_slopes=None if slopes is None else slopes.cpu().numpy())
+    out, lse = cabi.fwd(q, k, v, **kw)[:2]
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), **okw)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol("bf16", ro)
+    assert np.abs(lse.cpu().numpy() - rl).max() <= 1e-3
+    dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, **kw)
+    rdq, rdk, rdv, _ = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), ro, rl, **okw)
+    for got, ref in ((dq, rdq), (dk, rdk), (dv, rdv)):
+        assert np.abs(f32(got) - ref).max() <= 2 * ulp_tol("bf16", ref)
