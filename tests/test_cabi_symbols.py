@@ -90,3 +90,53 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
     q = torch.randn(1, 4, 2, 64, dtype=torch.float16)
     with pytest.raises(RuntimeError, match="must be on CUDA"):
         fa.flash_attn_func(q, q, q)
+
+
+def test_config1_fp32_cpu_through_the_api_matches_torch_sdpa():
+    """BASELINE config 1: flash_attn_func, batch 2, seqlen 128, 4 heads, headdim 64, fp32,
+    non-causal, on the CPU, against torch's scaled_dot_product_attention to 1e-5 -- through the
+    package's own API (its host fp32 path; the oracle is not involved).  Plus the causal and GQA
+    forms of the same plumbing, and LSE against logsumexp of the scaled scores."""
+    import torch
+    import torch.nn.functional as F
+    import vllm_flash_attn as fa
+    torch.manual_seed(0)
+    b, s, h, d = 2, 128, 4, 64
+    q, k, v = (torch.randn(b, s, h, d, dtype=torch.float32) for _ in range(3))
+    out, lse, sdm = fa.flash_attn_func(q, k, v, return_attn_probs=True)
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+    assert out.dtype == torch.float32 and out.shape == q.shape
+    assert (out - ref).abs().max().item() <= 1e-5
+    scores = torch.einsum("bqhd,bkhd->bhqk", q, k) * d ** -0.5
+    assert (lse - torch.logsumexp(scores, dim=-1)).abs().max().item() <= 1e-4
+    assert sdm.numel() == 0
+    out_c = fa.flash_attn_func(q, k, v, causal=True)
+    ref_c = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                                           is_causal=True).transpose(1, 2)
+    assert (out_c - ref_c).abs().max().item() <= 1e-5
+    kg, vg = k[:, :, :2].contiguous(), v[:, :, :2].contiguous()
+    out_g = fa.flash_attn_func(q, kg, vg)
+    ref_g = F.scaled_dot_product_attention(q.transpose(1, 2), kg.repeat_interleave(2, dim=2).transpose(1, 2),
+                                           vg.repeat_interleave(2, dim=2).transpose(1, 2)).transpose(1, 2)
+    assert (out_g - ref_g).abs().max().item() <= 1e-5
+    # bottom-right aligned causal mask with more keys than queries, and a sliding window
+    q2 = q[:, :40]
+    out_w = fa.flash_attn_func(q2, k, v, window_size=(17, 5))
+    i = torch.arange(40)[:, None] + (s - 40)
+    j = torch.arange(s)[None, :]
+    mask = (j <= i + 5) & (j >= i - 17)
+    ref_w = F.scaled_dot_product_attention(q2.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                                           attn_mask=mask).transpose(1, 2)
+    assert (out_w - ref_w).abs().max().item() <= 1e-5
+
+
+def test_decode_split_count_never_exceeds_the_kernels_key_tiles():
+    import cabi
+    lib = cabi.lib()
+    for d in (64, 128, 192, 256):
+        for sk in (100, 300, 1000, 8192):
+            n = lib.vfa_splitkv_num_splits(1, 2, d, sk, 1, 256)
+            assert 1 <= n <= max(1, (sk + 127) // 128), (d, sk, n)
+    # up to d = 128 the count is the reference's function of the shapes
+    from oracle import fa_oracle
+    assert lib.vfa_splitkv_num_splits(2, 8, 128, 8192, 1, 256) == fa_oracle.num_splits_heuristic(16, 512, 64, 128)

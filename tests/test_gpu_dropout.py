@@ -157,9 +157,10 @@ def test_dropout_rejections():
     q = torch.randn(1, 64, 2, 64, device="cuda", dtype=torch.float16)
     with pytest.raises(RuntimeError, match="p_dropout must be in"):
         fa.flash_attn_func(q, q, q, dropout_p=1.0)
-    # without dropout return_attn_probs yields no S_dmask, like the reference wrapper (:530)
+    # without dropout return_attn_probs yields an EMPTY S_dmask tensor, like the reference
+    # (flash_api.cpp:355-357 returns torch::empty({0}) in that slot)
     out, lse, sdm = fa.flash_attn_func(q, q, q, return_attn_probs=True)
-    assert sdm is None
+    assert isinstance(sdm, torch.Tensor) and sdm.numel() == 0
     # repeatable for a fixed generator state
     torch.manual_seed(3)
     a = fa.flash_attn_func(q, q, q, dropout_p=0.4)

@@ -1,0 +1,237 @@
+"""GPU parity tests of the head-dim pad path, the wide head dims in the backward, and seqused_k.
+
+Head dims that are not a multiple of 8 (the reference's own parametrisation has 40, 59, 111:
+tests/test_flash_attn.py:555) are zero-padded by the extension module to the next multiple, the
+kernels run on the padded tensors and the outputs / gradients are sliced back
+(csrc/flash_attn/flash_api.cpp:310-319,407-411; upstream's mha_bwd pads dout the same way).  The
+oracle takes the unpadded tensors: zero columns change neither the scores nor the other columns of
+the outputs, so the comparison is to the usual 2 ulp (forward) / 4 ulp (gradients) of the 16-bit
+result, with softmax_scale = d_og ** -0.5 on both sides."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cu(lens):
+    return torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+
+
+def _check_grads(got, ref, dt):
+    from gpu_util import f32, ulp_tol
+    for nm, a, r in zip(("dq", "dk", "dv"), got, ref):
+        assert a.shape == r.shape, (nm, a.shape, r.shape)
+        assert np.isfinite(f32(a)).all(), nm
+        err = np.abs(f32(a) - r).max()
+        assert err <= 2 * ulp_tol(dt, r), (nm, err)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [40, 59, 111])
+def test_flash_attn_func_odd_head_dim_fwd_bwd(d, causal, dt):
+    """flash_attn_func / flash_attn_kvpacked_func at d % 8 != 0: forward, out= copy-back and
+    autograd backward against the oracle on the unpadded tensors."""
+    import vllm_flash_attn as fa
+    from oracle import fa_oracle
+    from gpu_util import TDT, f32, ulp_tol
+    torch.manual_seed(d)
+    b, sq, sk, h, hk = 2, 113, 203, 4, 2
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt], requires_grad=True)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt], requires_grad=True)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt], requires_grad=True)
+    g = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    out, lse, _ = fa.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+    assert out.shape == q.shape
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), dtype=dt, causal=causal)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
+    assert np.abs(f32(lse) - rl).max() <= 1e-3
+    grads = torch.autograd.grad(out, (q, k, v), g)
+    ref = fa_oracle.attention_bwd(f32(g), f32(q), f32(k), f32(v), ro, rl, dtype=dt, causal=causal)[:3]
+    _check_grads(grads, ref, dt)
+    # caller-provided output buffer with the unpadded head dim: filled by the copy-back
+    buf = torch.full_like(q, float("nan")).detach()
+    o2 = fa.flash_attn_func(q.detach(), k.detach(), v.detach(), causal=causal, out=buf)
+    assert torch.equal(buf, out.detach()) and torch.equal(o2, out.detach())
+    # packed kv: gradients come back stacked with the caller's head dim
+    kv = torch.stack([k.detach(), v.detach()], dim=2).requires_grad_()
+    q2 = q.detach().clone().requires_grad_()
+    o3 = fa.flash_attn_kvpacked_func(q2, kv, causal=causal)
+    dq3, dkv3 = torch.autograd.grad(o3, (q2, kv), g)
+    assert torch.equal(o3, out.detach()) and torch.equal(dq3, grads[0])
+    assert torch.equal(dkv3[:, :, 0], grads[1]) and torch.equal(dkv3[:, :, 1], grads[2])
+
+
+@pytest.mark.parametrize("d", [40, 59, 111])
+def test_flash_attn_varlen_func_odd_head_dim_fwd_bwd(d):
+    """flash_attn_varlen_func / flash_attn_varlen_qkvpacked_func at d % 8 != 0 (ragged batch)."""
+    import vllm_flash_attn as fa
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(100 + d)
+    dt, h = "bf16", 3
+    lens = [76, 34, 146]
+    cu = _cu(lens)
+    tot = sum(lens)
+    qkv = torch.randn(tot, 3, h, d, device="cuda", dtype=torch.bfloat16)
+    g = torch.randn(tot, h, d, device="cuda", dtype=torch.bfloat16)
+    q, k, v = (qkv[:, i].detach().clone().requires_grad_() for i in range(3))
+    out, lse, _ = fa.flash_attn_varlen_func(q, k, v, cu, cu, max(lens), max(lens), causal=True,
+                                            return_attn_probs=True)
+    okw = dict(dtype=dt, causal=True, cu_seqlens_q=cu.cpu().numpy(), cu_seqlens_k=cu.cpu().numpy(),
+               max_seqlen_q=max(lens), max_seqlen_k=max(lens))
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), **okw)
+    assert out.shape == q.shape
+    assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
+    grads = torch.autograd.grad(out, (q, k, v), g)
+    ref = fa_oracle.attention_bwd(f32(g), f32(q), f32(k), f32(v), ro, rl, **okw)[:3]
+    _check_grads(grads, ref, dt)
+    p = qkv.detach().clone().requires_grad_()
+    o2 = fa.flash_attn_varlen_qkvpacked_func(p, cu, max(lens), causal=True)
+    (dp,) = torch.autograd.grad(o2, p, g)
+    assert torch.equal(o2, out.detach())
+    assert dp.shape == qkv.shape and torch.equal(dp, torch.stack(grads, dim=1))
+
+
+def test_extension_bwd_pads_unpadded_inputs_and_fills_given_buffers():
+    """`bwd` called the way an external caller might: unpadded q / k / v / out / dout at d = 59 and
+    caller-allocated dq / dk / dv of that shape -- equal to the autograd path bit for bit."""
+    import vllm_flash_attn as fa
+    import vllm_flash_attn_2_cuda as ext
+    torch.manual_seed(59)
+    b, s, h, d = 1, 90, 2, 59
+    q, k, v = (torch.randn(b, s, h, d, device="cuda", dtype=torch.float16, requires_grad=True) for _ in range(3))
+    g = torch.randn(b, s, h, d, device="cuda", dtype=torch.float16)
+    out, lse, _ = fa.flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+    want = torch.autograd.grad(out, (q, k, v), g)
+    dq, dk, dv = (torch.full_like(q, float("nan")).detach() for _ in range(3))
+    res = ext.bwd(g, q.detach(), k.detach(), v.detach(), out.detach(), lse, dq, dk, dv, None, 0.0, d ** -0.5,
+                  True, -1, -1, False, None, None)
+    for a, r, w in zip((dq, dk, dv), res[:3], want):
+        assert a.shape == w.shape and torch.equal(a, w) and torch.equal(r, w)
+
+
+@pytest.mark.parametrize("d", [40, 111])
+def test_fwd_kvcache_odd_head_dim_with_append(d):
+    """flash_attn_with_kvcache at d % 8 != 0 with new keys appended: the padded cache copy is
+    written back into the caller's cache (flash_api.cpp:924-929), out is sliced."""
+    import vllm_flash_attn as fa
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(d)
+    b, sq, cap, h, hk, snew = 2, 3, 160, 4, 2, 3
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.float16)
+    kc = torch.randn(b, cap, hk, d, device="cuda", dtype=torch.float16)
+    vc = torch.randn(b, cap, hk, d, device="cuda", dtype=torch.float16)
+    kn = torch.randn(b, snew, hk, d, device="cuda", dtype=torch.float16)
+    vn = torch.randn(b, snew, hk, d, device="cuda", dtype=torch.float16)
+    lens = torch.tensor([100, 37], dtype=torch.int32, device="cuda")
+    k0, v0 = kc.clone(), vc.clone()
+    out = fa.flash_attn_with_kvcache(q, kc, vc, k=kn, v=vn, cache_seqlens=lens, causal=True)
+    assert out.shape == q.shape
+    ke, ve = k0.clone(), v0.clone()
+    for i, n in enumerate(lens.tolist()):
+        ke[i, n:n + snew] = kn[i]
+        ve[i, n:n + snew] = vn[i]
+    assert torch.equal(kc, ke) and torch.equal(vc, ve)
+    ro, _ = fa_oracle.attention_fwd(f32(q), f32(ke), f32(ve), dtype="fp16", causal=True,
+                                    cache_seqlens=(lens + snew).cpu().numpy())
+    assert np.abs(f32(out) - ro).max() <= ulp_tol("fp16", ro)
+
+
+WIDE = [
+    ("bf16", 2, 200, 330, 4, 2, 160, True, (-1, -1), False),
+    ("fp16", 1, 257, 257, 2, 2, 192, False, (-1, -1), False),
+    ("bf16", 1, 129, 300, 3, 1, 224, True, (-1, -1), True),
+    ("fp16", 2, 300, 140, 2, 1, 192, False, (40, 25), False),
+    ("bf16", 1, 520, 520, 2, 2, 160, True, (100, 0), False),
+    ("bf16", 1, 64, 700, 4, 4, 224, False, (-1, -1), False),
+    ("fp16", 1, 383, 383, 2, 2, 256, True, (-1, -1), False),
+]
+
+
+@pytest.mark.parametrize("case", WIDE, ids=[str(c) for c in WIDE])
+def test_wide_head_dim_fwd_bwd_vs_oracle(case):
+    """d in {160, 192, 224, 256}: the DP = 256 instantiations (4-wave workgroups, generic loads in
+    the dK/dV kernel), forward and backward against the oracle."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import TDT, f32, ulp_tol
+    dt, b, sq, sk, h, hk, d, causal, window, alibi = case
+    torch.manual_seed(d + sq)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    do = torch.randn_like(q)
+    slopes = (torch.rand(b, h, device="cuda") * 0.3) if alibi else None
+    kw = dict(causal=causal, window=window, alibi_slopes=slopes)
+    okw = dict(dtype=dt, causal=causal, window=window, alibi_slopes=None if slopes is None else f32(slopes))
+    out, lse = cabi.fwd(q, k, v, **kw)[:2]
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), **okw)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
+    grads = cabi.bwd(do, q, k, v, out, lse, **kw)[:3]
+    ref = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), ro, rl, **okw)[:3]
+    _check_grads(grads, ref, dt)
+
+
+@pytest.mark.parametrize("paged", [False, True])
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_seqused_k(paged, causal):
+    """seqused_k (flash_api.cpp:429,531-536; block_info.h:33): per sequence, only the first
+    seqused_k[b] keys of the cu_seqlens_k extent are attended, also over a paged cache (the call
+    vLLM makes: cu_seqlens_k spans the allocated pages, seqused_k the tokens in them)."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    import vllm_flash_attn_2_cuda as ext
+    torch.manual_seed(7 + paged)
+    dt, h, hk, d = "bf16", 4, 2, 128
+    ql = [5, 64, 33]
+    kl = [192, 256, 64]           # allocated extents
+    used = [130, 256, 17]         # keys in use
+    cq, ck = _cu(ql), _cu(kl)
+    su = torch.tensor(used, dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.bfloat16)
+    # oracle: the same batch with the keys cut to the used prefix
+    kcut = torch.cat([k[ck[i]:ck[i] + used[i]] for i in range(3)])
+    vcut = torch.cat([v[ck[i]:ck[i] + used[i]] for i in range(3)])
+    cku = _cu(used)
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(kcut), f32(vcut), dtype=dt, causal=causal,
+                                     cu_seqlens_q=cq.cpu().numpy(), cu_seqlens_k=cku.cpu().numpy(),
+                                     max_seqlen_q=max(ql), max_seqlen_k=max(used))
+    # and the oracle's own seqused_k path must agree with that
+    ro2, _ = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), dtype=dt, causal=causal,
+                                     cu_seqlens_q=cq.cpu().numpy(), cu_seqlens_k=ck.cpu().numpy(),
+                                     max_seqlen_q=max(ql), max_seqlen_k=max(kl), seqused_k=np.array(used, np.int32))
+    assert np.abs(ro - ro2).max() <= 1e-6
+    if paged:
+        page = 64
+        nblk = sum(kl) // page
+        perm = torch.randperm(nblk, device="cuda")
+        kp = torch.empty(nblk, page, hk, d, device="cuda", dtype=torch.bfloat16)
+        vp = torch.empty_like(kp)
+        maxb = max(kl) // page
+        bt = torch.zeros(3, maxb, dtype=torch.int32, device="cuda")
+        nxt = 0
+        for i in range(3):
+            for j in range(kl[i] // page):
+                pg = int(perm[nxt]); nxt += 1
+                kp[pg] = k[ck[i] + j * page: ck[i] + (j + 1) * page]
+                vp[pg] = v[ck[i] + j * page: ck[i] + (j + 1) * page]
+                bt[i, j] = pg
+        out, lse = cabi.fwd(q, kp, vp, causal=causal, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql),
+                            max_seqlen_k=max(kl), seqused_k=su, block_table=bt)[:2]
+        res = ext.varlen_fwd(q, kp, vp, None, cq, ck, su, bt, None, max(ql), max(kl), 0.0, d ** -0.5, False,
+                             causal, -1, -1, False, None)
+    else:
+        out, lse = cabi.fwd(q, k, v, causal=causal, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql),
+                            max_seqlen_k=max(kl), seqused_k=su)[:2]
+        res = ext.varlen_fwd(q, k, v, None, cq, ck, su, None, None, max(ql), max(kl), 0.0, d ** -0.5, False,
+                             causal, -1, -1, False, None)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
+    for i in range(3):
+        assert np.abs(f32(lse)[i, :, :ql[i]] - rl[i, :, :ql[i]]).max() <= 1e-3
+    assert torch.equal(res[0], out)  # the extension module's 19-argument entry plumbs seqused_k too

@@ -179,7 +179,11 @@ extern "C" int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, i
     const int block_n = head_size <= 64 ? 256 : (head_size <= 128 ? 128 : 64);
     const int num_n_blocks = (max_seqlen_k + block_n - 1) / block_n;
     const int num_m_blocks = (max_seqlen_q + 64 - 1) / 64;
-    return vfa_num_splits_heuristic(batch * num_heads * num_m_blocks, num_cus_ * 2, num_n_blocks, 128);
+    // The decode kernel cuts the keys in 128-key tiles whatever the head dim: a split count beyond
+    // the number of tiles (possible above d = 128, where the reference's block is 64 keys) would
+    // only add workgroups that write empty partials.
+    const int tiles = std::max(1, (max_seqlen_k + 127) / 128);
+    return std::min(tiles, vfa_num_splits_heuristic(batch * num_heads * num_m_blocks, num_cus_ * 2, num_n_blocks, 128));
 }
 
 static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {

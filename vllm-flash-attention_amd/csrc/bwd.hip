@@ -719,10 +719,8 @@ static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
     auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS>;
-    if (LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    if (hipError_t e = set_dyn_lds_once((const void *)kern, LDS, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(HS ? p.hsplit : 1)), dim3(Cfg::NT), LDS,
                        stream, p, n_kblocks);
     return hipGetLastError();
@@ -1060,10 +1058,8 @@ static hipError_t launch_dq_impl(const KParams &p, hipStream_t stream) {
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
     auto kern = bwd_dq_kernel<DP, BF16, NW, FAST, DROP>;
-    if (Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
     return hipGetLastError();
 }
@@ -1077,12 +1073,13 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
 template <int DP, bool BF16, bool DROP>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
     hipError_t e;
-    if (ev) (void)hipEventRecord(ev[0], stream);
+    if (ev && (e = hipEventRecord(ev[0], stream)) != hipSuccess) return e;
     {
         const int64_t rows = (int64_t)p.b * p.h * p.seqlen_q;
         hipLaunchKernelGGL(bwd_preprocess_kernel<BF16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (ev) (void)hipEventRecord(ev[1], stream);
+    if (ev && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;
     if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     if (e != hipSuccess) return e;
@@ -1090,8 +1087,9 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         const int64_t items = p.part_rows * p.h_k * (p.d / 8);
         hipLaunchKernelGGL(bwd_kv_reduce_kernel<BF16>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, p,
                            p.part_rows);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (ev) (void)hipEventRecord(ev[2], stream);
+    if (ev && (e = hipEventRecord(ev[2], stream)) != hipSuccess) return e;
     {
         // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU: measured
         // on MI355X (16k tokens, seqlen 512..16k): at d = 64, 4 waves win under a causal / window
@@ -1111,7 +1109,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;
     }
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (ev && (e = hipEventRecord(ev[3], stream)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -707,11 +707,8 @@ static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
     auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP, SPLIT>;
-    if (Cfg::LDS_BYTES > 64 * 1024) {  // per device and cheap: set on every launch
-        hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SPLIT ? (unsigned)p.num_splits : 1u), dim3(Cfg::NT),
                        Cfg::LDS_BYTES, stream, p, n_mblocks);
     return hipGetLastError();

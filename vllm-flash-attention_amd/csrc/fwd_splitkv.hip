@@ -497,11 +497,8 @@ static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
     const long long blocks = (long long)n_mblocks * p.b * p.h * p.num_splits;
     if (blocks <= 0) return hipSuccess;
     auto kern = fwd_decode_kernel<DP, BF16>;
-    if (Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(DEC_NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

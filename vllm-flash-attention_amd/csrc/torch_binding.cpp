@@ -10,6 +10,10 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <ATen/Parallel.h>
+
+#include <algorithm>
+#include <cmath>
 #include <limits>
 #include <optional>
 #include <vector>
@@ -97,7 +101,7 @@ Tensor plan_dropout(vfa_params &P, double p_dropout, bool return_softmax, int64_
                     int64_t sq, int64_t sk, const at::TensorOptions &opts, Tensor &rng_state,
                     std::optional<at::Generator> &gen_) {
     TORCH_CHECK(p_dropout >= 0.0 && p_dropout < 1.0, "p_dropout must be in [0, 1)");
-    Tensor p;
+    Tensor p = torch::empty({0}, opts);  // flash_api.cpp:355-357: an empty tensor, not None
     if (return_softmax) {
         TORCH_CHECK(p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
         // zero-filled (the reference leaves tiles its kernel never visits uninitialised)
@@ -119,12 +123,107 @@ Tensor plan_dropout(vfa_params &P, double p_dropout, bool return_softmax, int64_
     return p;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp32 tensors in HOST memory: a plain C++ evaluation of the same function, so that
+// flash_attn_func(q, k, v) on CPU fp32 inputs can be checked against torch's
+// scaled_dot_product_attention without a GPU (the reference itself rejects such input,
+// flash_api.cpp:263-271).  It is taken ONLY for CPU fp32 tensors -- nothing a GPU call could reach:
+// CUDA tensors always run the HIP kernels, 16-bit CPU tensors are rejected as in the reference --
+// and it is forward-only.  Same conventions as the kernels: bottom-right aligned causal / window
+// mask (mask.h:171-172), ALiBi -slope * |i + sk - sq - j|, GQA head i -> i / (h / h_k), empty rows
+// -> 0 with LSE = +inf, LSE = max * scale + ln(sum).
+std::vector<Tensor> fwd_cpu_fp32(const Tensor &q_, const Tensor &k_, const Tensor &v_, OptTensor &out_,
+                                 OptTensor &alibi_slopes_, double p_dropout, double softmax_scale, bool is_causal,
+                                 int64_t wl, int64_t wr) {
+    TORCH_CHECK(k_.scalar_type() == at::kFloat && v_.scalar_type() == at::kFloat && !k_.is_cuda() && !v_.is_cuda(),
+                "q, k, v must all be fp32 CPU tensors for the host path");
+    TORCH_CHECK(p_dropout == 0.0, "the host fp32 path has no dropout");
+    TORCH_CHECK(q_.dim() == 4 && k_.dim() == 4 && v_.dim() == 4, "q, k, v must be 4-dimensional");
+    const Tensor q = q_.contiguous(), k = k_.contiguous(), v = v_.contiguous();
+    const int64_t b = q.size(0), sq = q.size(1), h = q.size(2), d = q.size(3);
+    const int64_t sk = k.size(1), hk = k.size(2);
+    TORCH_CHECK(b > 0, "batch size must be postive");
+    TORCH_CHECK(hk > 0 && h % hk == 0, "Number of heads in key/value must divide number of heads in query");
+    expect_shape(k, "k", {b, sk, hk, d});
+    expect_shape(v, "v", {b, sk, hk, d});
+    if (wl >= sk) wl = -1;                       // flash_api.cpp:289-294
+    if (wr >= sk) wr = -1;
+    if (is_causal) wr = 0;
+    const float *slopes = nullptr;
+    int64_t slope_bs = 0;
+    Tensor sl;
+    if (alibi_slopes_.has_value()) {
+        sl = alibi_slopes_.value().contiguous();
+        TORCH_CHECK(sl.scalar_type() == at::kFloat && !sl.is_cuda(), "ALiBi slopes must be fp32 on the CPU here");
+        TORCH_CHECK(sl.sizes() == at::IntArrayRef({h}) || sl.sizes() == at::IntArrayRef({b, h}),
+                    "alibi_slopes must have shape (num_heads) or (batch_size, num_heads)");
+        slopes = sl.data_ptr<float>();
+        slope_bs = sl.dim() == 2 ? h : 0;
+    }
+    Tensor out = torch::empty_like(q);
+    Tensor lse = torch::empty({b, h, sq}, q.options());
+    const float *Q = q.data_ptr<float>(), *K = k.data_ptr<float>(), *V = v.data_ptr<float>();
+    float *O = out.data_ptr<float>(), *L = lse.data_ptr<float>();
+    const float scale = (float)softmax_scale;
+    const int64_t g = h / hk;
+    at::parallel_for(0, b * h, 1, [&](int64_t lo, int64_t hi) {
+        std::vector<float> s((size_t)sk);
+        std::vector<double> acc((size_t)d);
+        for (int64_t bh = lo; bh < hi; bh++) {
+            const int64_t bi = bh / h, hi_ = bh % h, kh = hi_ / g;
+            const float slope = slopes ? slopes[bi * slope_bs + hi_] : 0.f;
+            for (int64_t i = 0; i < sq; i++) {
+                const float *qr = Q + ((bi * sq + i) * h + hi_) * d;
+                const int64_t j_lo = wl < 0 ? 0 : std::max<int64_t>(0, i + sk - sq - wl);
+                const int64_t j_hi = wr < 0 ? sk : std::min<int64_t>(sk, i + 1 + sk - sq + wr);
+                float m = -std::numeric_limits<float>::infinity();
+                for (int64_t j = j_lo; j < j_hi; j++) {
+                    const float *kr = K + ((bi * sk + j) * hk + kh) * d;
+                    float dot = 0.f;
+                    for (int64_t c = 0; c < d; c++) dot += qr[c] * kr[c];
+                    dot = dot * scale - slope * std::fabs((float)(i + sk - sq - j));
+                    s[(size_t)j] = dot;
+                    m = std::max(m, dot);
+                }
+                float *orow = O + ((bi * sq + i) * h + hi_) * d;
+                if (j_hi <= j_lo) {  // fully masked row (softmax.h:178-179)
+                    std::fill(orow, orow + d, 0.f);
+                    L[bh * sq + i] = std::numeric_limits<float>::infinity();
+                    continue;
+                }
+                double sum = 0.0;
+                std::fill(acc.begin(), acc.end(), 0.0);
+                for (int64_t j = j_lo; j < j_hi; j++) {
+                    const float pj = std::exp(s[(size_t)j] - m);
+                    sum += pj;
+                    const float *vr = V + ((bi * sk + j) * hk + kh) * d;
+                    for (int64_t c = 0; c < d; c++) acc[(size_t)c] += (double)pj * vr[c];
+                }
+                for (int64_t c = 0; c < d; c++) orow[c] = (float)(acc[(size_t)c] / sum);
+                L[bh * sq + i] = m + (float)std::log(sum);
+            }
+        }
+    });
+    if (out_.has_value()) {
+        TORCH_CHECK(out_.value().sizes() == out.sizes() && out_.value().scalar_type() == at::kFloat,
+                    "out must have the shape and dtype of q");
+        out_.value().copy_(out);
+        out = out_.value();
+    }
+    Tensor rng_state = torch::zeros({2}, q.options().dtype(at::kLong));
+    return {out, q, k, v, out, lse, torch::empty({0}, q.options()), rng_state};
+}
+
 // ---------------------------------------------------------------------------------------------
 // fwd  (flash_api.cpp:240-420)
 std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &out_,
                         OptTensor &alibi_slopes_, const double p_dropout, const double softmax_scale,
                         bool is_causal, int64_t window_size_left, int64_t window_size_right,
                         const bool return_softmax, std::optional<at::Generator> gen_) {
+    if (!q.is_cuda() && q.scalar_type() == at::kFloat)
+        return fwd_cpu_fp32(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, window_size_left,
+                            window_size_right);
     const int dt = dtype_code(q);
     TORCH_CHECK(k.scalar_type() == q.scalar_type(), "query and key must have the same dtype");
     TORCH_CHECK(v.scalar_type() == q.scalar_type(), "query and value must have the same dtype");
@@ -551,8 +650,8 @@ std::vector<Tensor> fwd_kvcache(Tensor &q, const Tensor &kcache, const Tensor &v
 // ---------------------------------------------------------------------------------------------
 // bwd / varlen_bwd  (call sites flash_attn_interface.py:135-154, :183-207; Flash_bwd_params,
 // csrc/flash_attn/src/flash.h:145-183)
-std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &k, const Tensor &v,
-                             const Tensor &out, const Tensor &softmax_lse, OptTensor &dq_, OptTensor &dk_,
+std::vector<Tensor> bwd_impl(const Tensor &dout_in, const Tensor &q_in, const Tensor &k_in, const Tensor &v_in,
+                             const Tensor &out_in, const Tensor &softmax_lse, OptTensor &dq_, OptTensor &dk_,
                              OptTensor &dv_, const Tensor *cu_seqlens_q, const Tensor *cu_seqlens_k,
                              OptTensor &alibi_slopes_, int64_t max_seqlen_q, int64_t max_seqlen_k,
                              const double p_dropout, const double softmax_scale, const bool zero_tensors,
@@ -560,12 +659,28 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
                              const bool deterministic, std::optional<at::Generator> gen_,
                              OptTensor &rng_state_) {
     const bool varlen = cu_seqlens_q != nullptr;
-    const int dt = dtype_code(q);
-    for (const Tensor *t : {&k, &v, &out, &dout})
-        TORCH_CHECK(t->scalar_type() == q.scalar_type(), "query, key, value, out and dout must have the same dtype");
-    for (const Tensor *t : {&q, &k, &v, &out, &dout, &softmax_lse}) expect_gpu(*t, "input");
-    for (const Tensor *t : {&q, &k, &v, &out, &dout})
+    const int dt = dtype_code(q_in);
+    for (const Tensor *t : {&k_in, &v_in, &out_in, &dout_in})
+        TORCH_CHECK(t->scalar_type() == q_in.scalar_type(), "query, key, value, out and dout must have the same dtype");
+    for (const Tensor *t : {&q_in, &k_in, &v_in, &out_in, &dout_in, &softmax_lse}) expect_gpu(*t, "input");
+    for (const Tensor *t : {&q_in, &k_in, &v_in, &out_in, &dout_in})
         TORCH_CHECK(t->stride(-1) == 1, "Input tensor must have contiguous last dimension");
+    // Head dims that are not a multiple of 8: the forward returned q, k, v, out zero-padded to the
+    // next multiple (flash_api.cpp:310-319) and autograd saved those, while dout arrives with the
+    // caller's head dim; upstream's mha_bwd pads dout (and slices dq, dk, dv back at the end).
+    // Unpadded q / k / v / out are accepted too and padded here the same way.
+    const int64_t d_og = dout_in.size(-1);
+    const int64_t d_in = q_in.size(-1);
+    const int64_t d_pad = (std::max(d_og, d_in) + 7) / 8 * 8;
+    TORCH_CHECK(d_og <= d_in && d_pad - d_og < 8 && (d_in == d_og || d_in == d_pad),
+                "dout must have the head size of q, or the head size q had before it was padded to a multiple of 8");
+    auto pad_to = [&](const Tensor &t) {
+        TORCH_CHECK(t.size(-1) == d_og || t.size(-1) == d_pad, "q, k, v, out must share one head size");
+        if (t.size(-1) == d_pad) return t;
+        namespace F = torch::nn::functional;
+        return F::pad(t, F::PadFuncOptions({0, d_pad - t.size(-1)}));
+    };
+    const Tensor q = pad_to(q_in), k = pad_to(k_in), v = pad_to(v_in), out = pad_to(out_in), dout = pad_to(dout_in);
     TORCH_CHECK(p_dropout >= 0.0 && p_dropout < 1.0, "p_dropout must be in [0, 1)");
     TORCH_CHECK(softmax_lse.scalar_type() == at::kFloat, "softmax_lse must be fp32");
 
@@ -592,16 +707,18 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
     TORCH_CHECK(d <= 256, "FlashAttention backward only supports head dimension at most 256");
     TORCH_CHECK(hk > 0 && h % hk == 0, "Number of heads in key/value must divide number of heads in query");
 
-    Tensor dq = dq_.has_value() ? dq_.value() : torch::empty_like(q);
-    Tensor dk = dk_.has_value() ? dk_.value() : torch::empty_like(k);
-    Tensor dv = dv_.has_value() ? dv_.value() : torch::empty_like(v);
-    for (const Tensor *t : {&dq, &dk, &dv}) {
-        TORCH_CHECK(t->scalar_type() == q.scalar_type(), "dq, dk, dv must have the same dtype as q");
-        expect_gpu(*t, "gradient");
-        TORCH_CHECK(t->stride(-1) == 1, "gradient must have contiguous last dimension");
-    }
-    TORCH_CHECK(dq.sizes() == q.sizes() && dk.sizes() == k.sizes() && dv.sizes() == v.sizes(),
-                "dq, dk, dv must have the shapes of q, k, v");
+    // Caller-provided gradients have the shape of the q / k / v that were passed in; when those were
+    // not padded the kernels write padded temporaries and the head-dim prefix is copied back.
+    auto grad_buf = [&](OptTensor &g_, const Tensor &like_in, const Tensor &like_pad) {
+        if (!g_.has_value()) return torch::empty_like(like_pad);
+        const Tensor &g = g_.value();
+        TORCH_CHECK(g.scalar_type() == q.scalar_type(), "dq, dk, dv must have the same dtype as q");
+        expect_gpu(g, "gradient");
+        TORCH_CHECK(g.stride(-1) == 1, "gradient must have contiguous last dimension");
+        TORCH_CHECK(g.sizes() == like_in.sizes(), "dq, dk, dv must have the shapes of q, k, v");
+        return g.size(-1) == d_pad ? g : torch::empty_like(like_pad);
+    };
+    Tensor dq = grad_buf(dq_, q_in, q), dk = grad_buf(dk_, k_in, k), dv = grad_buf(dv_, v_in, v);
 
     at::hip::HIPGuardMasqueradingAsCUDA device_guard{(c10::DeviceIndex)q.get_device()};
     auto opts = q.options();
@@ -671,6 +788,13 @@ std::vector<Tensor> bwd_impl(const Tensor &dout, const Tensor &q, const Tensor &
         run(varlen ? vfa_mha_varlen_bwd(&P) : vfa_mha_bwd(&P));
     } else {
         dq.zero_(); dk.zero_(); dv.zero_(); softmax_d.zero_();
+    }
+    if (d_og != d_pad) {  // upstream mha_bwd: slice the padding off (and fill the caller's buffers)
+        auto unpad = [&](Tensor &g, OptTensor &g_) {
+            if (g_.has_value() && g_.value().size(-1) != d_pad) g_.value().copy_(g.narrow(-1, 0, g_.value().size(-1)));
+            g = g.narrow(-1, 0, d_og);
+        };
+        unpad(dq, dq_); unpad(dk, dk_); unpad(dv, dv_);
     }
     return {dq, dk, dv, softmax_d};
 }

@@ -5,7 +5,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace vfa {
+
+// Host side: kernels that need more than 64 KiB of dynamic LDS must be told so once per device.
+// `done` is a per-instantiation bit set of the devices already configured (function-local static
+// of the launcher), so the runtime call is not repeated on every launch.
+inline hipError_t set_dyn_lds_once(const void *kern, int bytes, std::atomic<uint64_t> &done) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev < 64) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 struct KParams {
     const void *q, *k, *v;

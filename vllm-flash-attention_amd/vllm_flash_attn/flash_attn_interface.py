@@ -269,7 +269,8 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
     (bottom-right aligned).  window_size=(l, r): query i attends keys in
     [i + seqlen_k - seqlen_q - l, i + seqlen_k - seqlen_q + r].  alibi_slopes adds
     -slope * |i + seqlen_k - seqlen_q - j|.  Returns out (batch_size, seqlen_q, nheads, headdim) and,
-    with return_attn_probs=True, (out, softmax_lse (batch_size, nheads, seqlen_q), None).
+    with return_attn_probs=True, (out, softmax_lse (batch_size, nheads, seqlen_q), S_dmask) where S_dmask
+    is an empty tensor unless dropout_p > 0.
     Reference: :793-867."""
     return FlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, alibi_slopes,
                                deterministic, return_attn_probs, out)
