@@ -6,10 +6,16 @@
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one forward + one backward pass of the attention op over one synthetic batch
-(torch.randn inputs resident in HBM), called through the C ABI of libvfa_hip.so.  Every rank runs
-the full headline batch (weak scaling, no collective on the data path: batches are independent);
-rank 0 prints ONE JSON line.  FLOP convention: the reference's benchmarks/benchmark_flash_attention.py
-:27-30 (4*b*s^2*h*d, /2 causal; backward = 2.5x forward).
+(torch.randn inputs resident in HBM), called through the C ABI of libvfa_hip.so.  One process per
+GPU: under torch.distributed.run the ranks come from the environment; started plainly with
+--gpus N > 1 this script starts N ranks of itself (before it touches a GPU) and relays rank 0's
+line.  --scaling weak (default): every rank runs the full per-GPU batch; --scaling strong: the
+global batch is sharded contiguously over the ranks (shard_range; ragged batches are cut at
+sequence boundaries balancing the visible query-key pairs, balanced_varlen_split).  No collective
+touches the data path (batch entries are independent); the process group carries the timing
+barrier, the max of the elapsed time and the sum of the work.  Rank 0 prints ONE JSON line.  FLOP
+convention: the reference's benchmarks/benchmark_flash_attention.py:27-30 (4*b*s^2*h*d, /2 causal;
+backward = 2.5x forward).
 
 Other workloads (--workload): c2 (b4 s2048 h16 d64 causal fwd), c3_fwd, c5 (kv-cache decode, GB/s).
 """
@@ -92,6 +98,58 @@ def shard_range(n, world, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def balanced_varlen_split(seqlens_q, seqlens_k, causal, window, world):
+    """Cuts a ragged batch into `world` contiguous runs of whole sequences so that the largest
+    run's visible query-key pair count (the masked FLOP count up to 4*h*d) is as small as possible
+    (exact: dynamic programme over the prefix sums).  Returns [(start, stop)] per rank; a rank may
+    get an empty run when there are fewer sequences than ranks."""
+    n = len(seqlens_q)
+    w = [visible_pairs([a], [b], causal, window) for a, b in zip(seqlens_q, seqlens_k)]
+    pre = [0]
+    for x in w:
+        pre.append(pre[-1] + x)
+    INF = float("inf")
+    # best[r][i]: minimal max-load cutting the first i sequences into r runs
+    best = [[INF] * (n + 1) for _ in range(world + 1)]
+    cut = [[0] * (n + 1) for _ in range(world + 1)]
+    best[0][0] = 0
+    for r in range(1, world + 1):
+        for i in range(n + 1):
+            for j in range(i + 1):
+                c = max(best[r - 1][j], pre[i] - pre[j])
+                if c < best[r][i]:
+                    best[r][i], cut[r][i] = c, j
+    bounds, i = [], n
+    for r in range(world, 0, -1):
+        j = cut[r][i]
+        bounds.append((j, i))
+        i = j
+    return bounds[::-1]
+
+
+def launch_ranks(n, argv):
+    """Starts n ranks of this script on this node (one per GPU, rendezvous on 127.0.0.1), relays
+    rank 0's output and returns the first non-zero exit code.  Called before anything in this
+    process has touched a GPU; the children are fresh interpreters, nothing is re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk_:
+        sk_.bind(("127.0.0.1", 0))
+        port = sk_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        code = pr.wait()
+        rc = rc or code
+    return rc
+
+
 def dist_setup(backend):
     """Joins the process group when launched by torch.distributed.run; returns (dist or None, rank,
     world, local_rank).  The group is used only for the timing barrier and the max-over-ranks."""
@@ -110,6 +168,14 @@ def max_over_ranks(dist, seconds, device):
         return seconds
     t = torch.tensor([seconds], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def sum_over_ranks(dist, x, device):
+    if dist is None:
+        return x
+    t = torch.tensor([x], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.item()
 
 
@@ -225,16 +291,80 @@ def cpu_sdpa(b, sq, sk, h, d, causal, mode):
     return res
 
 
-def main():
+GLOBAL_BATCH = {"c5": 1024}   # strong scaling: the decode configuration's 1024 sequences over all ranks
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs the per-GPU batch; strong: the global batch is sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sdpa", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="launcher / sharding / aggregation self-test on CPU ranks (gloo); the step is a stub, "
+                         "no attention work is timed and the line says so")
+    return ap.parse_args(argv)
 
+
+def main(argv=None):
+    args = parse_args(argv)
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world == 0 and args.gpus > 1:
+        # started plainly: become the launcher.  torch.cuda.device_count() does not initialise the GPU.
+        if not args.selftest_cpu and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        sys.exit(launch_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv)))
+    if env_world > 0 and env_world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={env_world}: start one rank per GPU")
+    if args.selftest_cpu:
+        return selftest_rank(args)
+    return run_rank(args)
+
+
+def selftest_rank(args):
+    """One CPU rank of the launcher self-test: the real rendezvous (gloo), sharding, barrier,
+    max-over-ranks, work sum and output line of run_rank around a stub step."""
+    import numpy as np
+    dist, rank, world, _ = dist_setup("gloo")
+    dev = torch.device("cpu")
+    b = 8
+    lo, hi = shard_range(b, world, rank) if args.scaling == "strong" else (0, b)
+    a = np.ones((64, 64), np.float32)
+    work = float(hi - lo)
+
+    def step():
+        for _ in range(lo, hi):
+            a @ a
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0, dev)
+    total = sum_over_ranks(dist, work, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (stub step, batch entries per second)",
+                          "value": total * args.steps / elapsed, "unit": "entries/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                          "dtype": "f32", "data": "launcher self-test: no attention work",
+                          "config": {"workload": "selftest", "entries_all_ranks": total}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP extension has no CPU fallback)")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -244,6 +374,17 @@ def main():
     hip = Hip()
 
     b, sq, sk, h, hk, d, dtype, causal, mode = WORKLOADS[args.workload]
+    strong = args.scaling == "strong"
+    c4_lens = C4_SEQLENS
+    if strong:
+        if mode == "varlen_fwd":
+            lo, hi = balanced_varlen_split(C4_SEQLENS, C4_SEQLENS, True, C4_WINDOW, world)[rank]
+            c4_lens = C4_SEQLENS[lo:hi]
+        else:
+            lo, hi = shard_range(GLOBAL_BATCH.get(args.workload, b), world, rank)
+            b = hi - lo
+        if (mode == "varlen_fwd" and not c4_lens) or b == 0:
+            raise SystemExit(f"rank {rank}: empty shard (more ranks than batch entries)")
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(rank)
@@ -257,7 +398,7 @@ def main():
 
     extra = {}
     if mode == "varlen_fwd":
-        lens = C4_SEQLENS
+        lens = c4_lens
         total = sum(lens)
         cu = torch.tensor([0] + list(__import__("itertools").accumulate(lens)), dtype=torch.int32, device=dev)
         q = torch.randn(total, h, d, device=dev, dtype=tdt)
@@ -338,7 +479,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, elapsed, dev)
-    value = aggregate(work, K, world, elapsed, scale)
+    # all ranks' work over the slowest rank's time (shards may differ by one entry)
+    value = sum_over_ranks(dist, work, dev) * K / elapsed / scale
 
     # ---- dominant-kernel duration with HIP events on the launch stream (rank 0, after the timed
     # region so that the region itself carries no instrumentation) ----
@@ -414,10 +556,11 @@ def main():
     if rank == 0:
         line = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: b{b} sq{sq} sk{sk} h{h}/{hk} d{d} {dtype} causal={causal} {mode}",
-                       "per_gpu_batch": b, "parallelism": f"batch-sharded replicas x{world}, no collective"},
+                       "per_gpu_batch": len(c4_lens) if mode == "varlen_fwd" else b,
+                       "parallelism": f"batch-sharded replicas x{world}, no collective"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

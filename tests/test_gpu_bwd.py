@@ -429,3 +429,49 @@ def test_forward_backward_is_graph_capturable():
     eager = step()
     for a, c in zip(captured, eager):
         assert torch.equal(a, c)
+
+
+RACE_CASES = [(128, 1, 239, False, 0.0), (59, 799, 3, True, 0.0), (64, 257, 257, True, 0.17),
+              (128, 1024, 1024, True, 0.0), (96, 1024, 128, False, 0.17), (256, 384, 384, True, 0.0)]
+
+
+@pytest.mark.parametrize("d,sq,sk,causal,dropout_p", RACE_CASES, ids=[str(c) for c in RACE_CASES])
+def test_race_condition_250_runs(d, sq, sk, causal, dropout_p):
+    """The reference's race test at its own counts (tests/test_flash_attn.py:2135-2173): batch 60,
+    4 heads, fp16, forward + autograd backward 250 times with the same generator seed; out, lse,
+    dk, dv must be bitwise equal every time -- and so must dq here (no atomics), where the
+    reference only asks for allclose."""
+    import vllm_flash_attn as fa
+    torch.random.manual_seed(0)
+    q = torch.randn(60, sq, 4, d, device="cuda", dtype=torch.float16, requires_grad=True)
+    k = torch.randn(60, sk, 4, d, device="cuda", dtype=torch.float16, requires_grad=True)
+    v = torch.randn(60, sk, 4, d, device="cuda", dtype=torch.float16, requires_grad=True)
+    torch.random.manual_seed(42)
+    out0, lse0, _ = fa.flash_attn_func(q, k, v, dropout_p, causal=causal, return_attn_probs=True)
+    g = torch.randn_like(out0)
+    dq0, dk0, dv0 = torch.autograd.grad(out0, (q, k, v), g)
+    for _ in range(250):
+        torch.random.manual_seed(42)
+        out, lse, _ = fa.flash_attn_func(q, k, v, dropout_p, causal=causal, return_attn_probs=True)
+        assert torch.equal(out, out0) and torch.equal(lse, lse0)
+        dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
+        assert torch.equal(dv, dv0) and torch.equal(dk, dk0) and torch.equal(dq, dq0)
+
+
+@pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])
+def test_deterministic_backward_50_runs(causal, local):
+    """deterministic=True, 50 backward passes bitwise equal (tests/test_flash_attn.py:2349-2375),
+    GQA so that dk / dv are sums over the group's heads."""
+    import vllm_flash_attn as fa
+    torch.random.manual_seed(0)
+    b, sq, sk, h, hk, d = 4, 239, 1023, 9, 3, 128
+    window = (57, 33) if local else (-1, -1)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    out = fa.flash_attn_func(q, k, v, 0.0, causal=causal, window_size=window, deterministic=True)
+    g = torch.randn_like(out)
+    dq0, dk0, dv0 = torch.autograd.grad(out, (q, k, v), g, retain_graph=True)
+    for _ in range(50):
+        dq, dk, dv = torch.autograd.grad(out, (q, k, v), g, retain_graph=True)
+        assert torch.equal(dv, dv0) and torch.equal(dk, dk0) and torch.equal(dq, dq0)

@@ -275,7 +275,7 @@ def test_repeatable_and_batch_independent():
     k = torch.randn(4, 1024, 2, 128, device="cuda", dtype=torch.bfloat16)
     v = torch.randn(4, 1024, 2, 128, device="cuda", dtype=torch.bfloat16)
     o0, l0 = _cabi().fwd(q, k, v, causal=True)
-    for _ in range(20):
+    for _ in range(250):
         o1, l1 = _cabi().fwd(q, k, v, causal=True)
         assert torch.equal(o0, o1) and torch.equal(l0, l1)
     o2, l2 = _cabi().fwd(q[1:2].contiguous(), k[1:2].contiguous(), v[1:2].contiguous(), causal=True)

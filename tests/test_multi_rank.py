@@ -66,3 +66,63 @@ def test_two_ranks_gloo_sharded_equals_unsharded():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get("equal") is True
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` started plainly (no WORLD_SIZE) must run TWO ranks: the launcher,
+    the gloo rendezvous, the shard of each rank, the max / sum over ranks and the one JSON line of
+    rank 0 are exercised here on CPU ranks around a stub step (--selftest-cpu); the GPU ranks run
+    the same code with the attention step in its place."""
+    import json
+    for scaling, entries in (("weak", 16.0), ("strong", 8.0)):
+        r = _run_bench("--gpus", "2", "--selftest-cpu", "--steps", "3", "--warmup", "1", "--scaling", scaling)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout            # rank 0 only
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["steps"] == 3
+        assert line["config"]["entries_all_ranks"] == entries   # weak: 8 per rank; strong: 8 in all
+        assert line["value"] > 0
+
+
+def test_bench_gpus_flag_fails_cleanly_without_the_gpus():
+    """Asking for more GPUs than the node has is an error, not a silent one-rank run; so is a
+    --gpus that contradicts the launcher's WORLD_SIZE."""
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("node has the GPUs")
+    r = _run_bench("--gpus", "2")
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+    r = _run_bench("--gpus", "2", "--selftest-cpu", env={"WORLD_SIZE": "4", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_balanced_varlen_split():
+    """Ragged batches are cut at sequence boundaries so that the most loaded rank has as few
+    visible query-key pairs as a contiguous cut allows."""
+    sys.path.insert(0, ROOT)
+    import bench
+    lens = bench.C4_SEQLENS
+    load = [bench.visible_pairs([n], [n], True, bench.C4_WINDOW) for n in lens]
+    for w in (1, 2, 4, 8):
+        parts = bench.balanced_varlen_split(lens, lens, True, bench.C4_WINDOW, w)
+        assert len(parts) == w and parts[0][0] == 0 and parts[-1][1] == len(lens)
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        worst = max(sum(load[a:b]) for a, b in parts)
+        # brute force over all contiguous cuts
+        import itertools
+        best = min(max(sum(load[a:b]) for a, b in zip((0,) + c, c + (len(lens),)))
+                   for c in itertools.combinations_with_replacement(range(len(lens) + 1), w - 1))
+        assert worst == best
+    # two ranks: the 8192-token sequence alone is NOT half of the windowed work
+    assert bench.balanced_varlen_split(lens, lens, True, bench.C4_WINDOW, 2)[0][1] >= 2
