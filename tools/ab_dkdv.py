@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing, in one process, of the two dK/dV kernels (8 waves x 32 keys vs 4 waves x
+64 keys) through vfa_debug_set_tuning (development tool).  Prints the median dK/dV and dQ kernel
+times per shape and variant, and checks that both variants give the same dk / dv to 1 ulp."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import ctypes as C
+import torch
+import cabi
+import bench
+
+
+def main():
+    hip = bench.Hip()
+    lib = cabi.lib()
+    torch.manual_seed(0)
+    shapes = [(8, 4096, 32, 32, 128, True, "bf16"), (8, 4096, 32, 32, 128, False, "bf16"),
+              (4, 4096, 32, 8, 128, True, "bf16"), (2, 8192, 16, 16, 128, True, "bf16"),
+              (16, 1024, 16, 16, 128, True, "bf16"), (32, 512, 16, 16, 128, True, "bf16"),
+              (4, 2048, 16, 16, 64, True, "bf16"), (8, 4096, 32, 32, 64, True, "bf16")]
+    if len(sys.argv) > 1:
+        shapes = [shapes[int(a)] for a in sys.argv[1:]]
+    stream = torch.cuda.current_stream().cuda_stream
+    variants = [1, 2]
+    for (b, s, h, hk, d, causal, dt) in shapes:
+        tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+        q = torch.randn(b, s, h, d, device="cuda", dtype=tdt)
+        k = torch.randn(b, s, hk, d, device="cuda", dtype=tdt)
+        v = torch.randn(b, s, hk, d, device="cuda", dtype=tdt)
+        do = torch.randn_like(q)
+        out = torch.empty_like(q)
+        lse = torch.empty(b, h, s, device="cuda", dtype=torch.float32)
+        dq = torch.empty_like(q)
+        sd = torch.empty(b, h, (s + 127) // 128 * 128, device="cuda", dtype=torch.float32)
+        acc = torch.empty(1, device="cuda", dtype=torch.float32)
+        Pf = bench.build_params(cabi, q, k, v, out, lse, causal, stream)
+        cabi.call("vfa_mha_fwd", Pf)
+        res, times = {}, {}
+        for var in variants:
+            dk, dv = torch.empty_like(k), torch.empty_like(v)
+            res[var] = (dk, dv, bench.build_params(cabi, q, k, v, out, lse, causal, stream, do, dq, dk, dv, sd, acc))
+            times[var] = []
+        n = 7
+        for rnd in range(n + 2):
+            for var in variants:
+                lib.vfa_debug_set_tuning(0, var)
+                Pb = res[var][2]
+                ev = (C.c_void_p * 4)(*[hip.event() for _ in range(4)])
+                Pb.stage_events = C.cast(ev, C.c_void_p)
+                cabi.call("vfa_mha_bwd", Pb)
+                torch.cuda.synchronize()
+                if rnd >= 2:
+                    times[var].append((hip.elapsed_ms(C.c_void_p(ev[1]), C.c_void_p(ev[2])),
+                                       hip.elapsed_ms(C.c_void_p(ev[2]), C.c_void_p(ev[3]))))
+        lib.vfa_debug_set_tuning(0, 0)
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        f = bench.fwd_flops(b, s, s, h, d, causal)
+        line = f"b{b} s{s} h{h}/{hk} d{d} causal={causal}:"
+        for var in variants:
+            t = med([x[0] for x in times[var]])
+            line += f"  v{var} dkdv {t:.3f} ms ({2 * f / t / 1e9:.0f} TF exec)"
+        dk1, dv1 = res[1][0].float(), res[1][1].float()
+        dk2, dv2 = res[2][0].float(), res[2][1].float()
+        ek = (dk1 - dk2).abs().max().item() / max(1.0, dk1.abs().max().item())
+        ev_ = (dv1 - dv2).abs().max().item() / max(1.0, dv1.abs().max().item())
+        line += f"  | rel diff dk {ek:.2e} dv {ev_:.2e}  nan {int(torch.isnan(dk2).any() or torch.isnan(dv2).any())}"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,10 @@ OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
-               "bwd_drop.hip", "fwd_prefill_split.hip"]
+               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip"]
+# Kernels built for one wave per SIMD (up to 512 registers): MFMA results that vector instructions
+# consume must be allocated in the arch VGPRs, not forced into the accumulator half of the file.
+EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # the dropout translation units are one-line includes of the kernel sources
 EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"],
               "fwd_prefill_split.hip": ["fwd_prefill.hip"]}
@@ -51,7 +54,7 @@ def build_hip(force=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + hdrs + [os.path.join(CSRC, e) for e in EXTRA_DEPS.get(src, [])]):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
@@ -72,7 +75,8 @@ def build_stamp():
     objs = []
     for src in HIP_SOURCES:
         o = os.path.join(od, src.replace(".hip", ".o"))
-        subprocess.check_call([HIPCC] + HIP_FLAGS + ["-DVFA_STAMP", "-c", os.path.join(CSRC, src), "-o", o])
+        subprocess.check_call([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) +
+                              ["-DVFA_STAMP", "-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out

@@ -26,6 +26,12 @@ hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *sta
 
 using vfa::KParams;
 
+namespace vfa { int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
+// Development hook (not part of include/vfa.h): kernel-variant switches for A/B timing.
+extern "C" void vfa_debug_set_tuning(int idx, int value) {
+    if (idx >= 0 && idx < 8) vfa::g_tuning[idx] = value;
+}
+
 static thread_local std::string g_err;
 
 #define VFA_CHECK(cond, msg)      \

@@ -477,16 +477,36 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                                      ((p.is_causal || p.is_local) && (kw0 + 32 > q0 + 1 + sk - sq + p.wr)) ||
                                      (p.is_local && (kw0 < q0 + 31 + sk - sq - p.wl));
             if (masked_tile) {
+                // Register j of lane (r, hh) is local row roff(j) = (j & 3) + 8 (j >> 2) (a constant)
+                // + 4 hh of the sub-block, the lane's key is `col`.  Visible (mask.h:171-172) iff
+                //   col <  min(sk, row + 1 + sk - sq + wr)   <=>  roff >= col - shift - wr   (causal / local)
+                //   col >= row + sk - sq - wl                 <=>  roff <= col - shift + wl   (local)
+                //   row <  sq                                 <=>  roff <  sq - q0 - 4 hh
+                // with shift = q0 + 4 hh + sk - sq: one subtract and one unsigned compare per score
+                // against the lane's [lo_r, lo_r + span] window.
+                constexpr int BIG = 1 << 28;
+                const int shift = q0 + 4 * hh + sk - sq;
+                int lo_r = (p.is_causal || p.is_local) ? col - shift - p.wr : -BIG;
+                int hi_r = p.is_local ? col - shift + p.wl : BIG;
+                hi_r = min(hi_r, sq - q0 - 4 * hh - 1);
+                lo_r = max(lo_r, -BIG);
+                if (col >= sk || hi_r < lo_r) { lo_r = BIG; hi_r = BIG; }  // nothing visible
+                const unsigned span = (unsigned)(hi_r - lo_r);
+                if (has_alibi) {
+                    if (p.is_causal) {  // mask.h:180-181: + slope * col
+                        const float ab = alibi * (float)col;
+#pragma unroll
+                        for (int j = 0; j < 16; j++) s[j] += ab;
+                    } else {            // mask.h:183: - slope * |row + sk - sq - col|
+                        const int dc = shift - col;
+#pragma unroll
+                        for (int j = 0; j < 16; j++) s[j] -= alibi * fabsf((float)((j & 3) + 8 * (j >> 2) + dc));
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    const int row = q0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    float x = s[j];
-                    if (has_alibi)
-                        x = p.is_causal ? x + alibi * (float)col
-                                        : x - alibi * fabsf((float)(row + sk - sq - col));
-                    const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
-                    const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
-                    s[j] = (col >= lo && col < hi && row < sq) ? x : -INFINITY;
+                    const int roff = (j & 3) + 8 * (j >> 2);
+                    s[j] = ((unsigned)(roff - lo_r) <= span) ? s[j] : -INFINITY;
                 }
             }
             if constexpr (LSE_IN_ACC) {
@@ -1070,6 +1090,8 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
                               : launch_dq_impl<DP, BF16, NW, false>(p, stream);
 }
 
+hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream);  // bwd_dkdv_w64.hip
+
 template <int DP, bool BF16, bool DROP>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
     hipError_t e;
@@ -1080,7 +1102,15 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (ev && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;
-    if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
+    // 64 keys per wave at one wave per SIMD (bwd_dkdv_w64.hip) where it measured ahead of the 8-wave
+    // kernel: d = 128 on full (unmasked) attention over long key ranges (3-5 % there; level on causal
+    // sweeps, where its waves cannot skip pieces above the diagonal, and behind on short sequences,
+    // where its 256-key blocks leave CUs idle).  Both kernels produce the same bits.
+    const bool w64_ok = DP <= 128 && !DROP && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
+    const bool w64_pays = DP == 128 && !p.is_causal && !p.is_local && p.seqlen_k >= 2048 && p.seqlen_q >= 2048;
+    const bool w64 = w64_ok && (g_tuning[0] == 2 || (g_tuning[0] == 0 && w64_pays));
+    if (w64) e = run_bwd_dkdv_w64(p, stream);
+    else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     if (e != hipSuccess) return e;
     if (p.hsplit > 1) {

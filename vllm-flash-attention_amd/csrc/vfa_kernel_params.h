@@ -9,6 +9,11 @@
 
 namespace vfa {
 
+// Development switches (kernel-variant selection for A/B timing inside one process), set through
+// vfa_debug_set_tuning(); all zero = the shipped choices.
+//   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one
+extern int g_tuning[8];
+
 // Host side: kernels that need more than 64 KiB of dynamic LDS must be told so once per device.
 // `done` is a per-instantiation bit set of the devices already configured (function-local static
 // of the launcher), so the runtime call is not repeated on every launch.
