@@ -141,6 +141,19 @@ int vfa_mha_varlen_fwd(const vfa_params *p);
  * csrc/flash_attn/flash_api.cpp:671-937 (pybind name `fwd_kvcache`, :945). */
 int vfa_mha_fwd_kvcache(const vfa_params *p);
 
+/* vfa_mha_fwd_kvcache for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference, whose
+ * split scratch is two torch::empty calls inside set_params_splitkv (flash_api.cpp:212-215).
+ * Same arguments and results as vfa_mha_fwd_kvcache, except that softmax_lseaccum / oaccum are
+ * ignored: the split-KV partial results go to a static device array of
+ * VFA_NOALLOC_SCRATCH_BYTES that the library holds on every GPU it runs on.  num_splits == 0 picks
+ * the count like vfa_splitkv_num_splits, lowered until it fits; an explicit count whose partials
+ * (num_splits * b * h * seqlen_q * (d + 1) floats) exceed the array is rejected with
+ * VFA_ERR_INVALID.  Calls no hipMalloc / hipFree or other allocating routine.  All calls on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (different streams) race. */
+#define VFA_NOALLOC_SCRATCH_BYTES (32u << 20)
+int vfa_mha_fwd_kvcache_noalloc(const vfa_params *p);
+
 /* Backward, dense batch.  The reference fork exports no backward (flash_api.cpp:943); the
  * argument list is pinned by its Python call site vllm_flash_attn/flash_attn_interface.py:135-154
  * and the parameter block csrc/flash_attn/src/flash.h:145-183. */

@@ -47,7 +47,8 @@ class VfaParams(C.Structure):
 
 
 ENTRY_POINTS = ["vfa_mha_fwd", "vfa_mha_varlen_fwd", "vfa_mha_fwd_kvcache", "vfa_mha_bwd",
-                "vfa_mha_varlen_bwd"]
+                "vfa_mha_varlen_bwd", "vfa_mha_fwd_kvcache_noalloc"]
+NOALLOC_SCRATCH_BYTES = 32 << 20   # VFA_NOALLOC_SCRATCH_BYTES of include/vfa.h
 _lib = None
 
 
@@ -104,10 +105,13 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
         cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, seqused_k=None,
         cache_seqlens=None, cache_batch_idx=None, block_table=None, knew=None, vnew=None,
         rotary_cos=None, rotary_sin=None, rotary_interleaved=True, num_splits=1, kvcache=False,
-        out=None, p_dropout=0.0, philox_seed=0, philox_offset=0, return_softmax=False, rng_state=None):
+        out=None, p_dropout=0.0, philox_seed=0, philox_offset=0, return_softmax=False, rng_state=None,
+        noalloc=False):
     """Forward through the C ABI on torch CUDA tensors.  Returns (out, lse), plus s_dmask
     (b, h, seqlen_q_rounded, seqlen_k_rounded) with return_softmax.  Picks the entry point like the
-    reference's Python layer does: varlen if cu_seqlens_q, kvcache if asked, else fwd."""
+    reference's Python layer does: varlen if cu_seqlens_q, kvcache if asked, else fwd.  noalloc:
+    vfa_mha_fwd_kvcache_noalloc (split partials in the library's static device array; no split
+    scratch is allocated here)."""
     import torch
     P = VfaParams()
     keep = []
@@ -156,7 +160,7 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
     P.softmax_scale = float(softmax_scale if softmax_scale is not None else d ** -0.5)
     P.is_causal, P.window_size_left, P.window_size_right = int(causal), int(window[0]), int(window[1])
     P.num_splits = int(num_splits)
-    if num_splits > 1:
+    if num_splits > 1 and not noalloc:
         lacc = torch.empty(num_splits, b, h, sq, dtype=torch.float32, device=q.device)
         oacc = torch.empty(num_splits, b, h, sq, d, dtype=torch.float32, device=q.device)
         keep += [lacc, oacc]
@@ -179,7 +183,10 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
         r128 = lambda x: (x + 127) // 128 * 128
         sdm = torch.zeros(b, h, r128(sq), r128(sk), dtype=q.dtype, device=q.device)
         P.s_dmask, P.seqlen_q_rounded, P.seqlen_k_rounded = sdm.data_ptr(), r128(sq), r128(sk)
-    if varlen:
+    if noalloc:
+        assert not varlen and not return_softmax
+        call("vfa_mha_fwd_kvcache_noalloc", P)
+    elif varlen:
         call("vfa_mha_varlen_fwd", P)
     elif kvcache or cache_seqlens is not None or paged or knew is not None or cache_batch_idx is not None:
         call("vfa_mha_fwd_kvcache", P)

@@ -3,6 +3,7 @@
 // reference, minus everything that needs torch (that part lives in torch_binding.cpp).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -310,6 +311,85 @@ extern "C" int vfa_mha_fwd_kvcache(const vfa_params *p) {
     // flash_api.cpp:919: appending, cache_batch_idx and paged caches take the split kernel
     const bool force = p->knew || p->cache_batch_idx || p->block_table;
     return launch_fwd(p, k, force);
+}
+
+// ---------------------------------------------------------------------------------------------
+// vfa_mha_fwd_kvcache_noalloc: the split-KV partial results live in a file-scope device array
+// instead of caller-provided workspace, for callers that cannot allocate (HIP graph capture, tight
+// serving loops).  Every GPU the library runs on holds its own copy of the array at its own
+// address until the process ends; in host code the array's NAME is only a handle for
+// hipGetSymbolAddress -- the address kernels and copies use is the per-device pointer below.
+static __device__ __align__(256) float scratch[VFA_NOALLOC_SCRATCH_BYTES / sizeof(float)];
+
+static constexpr int kMaxDevices = 64;
+static std::atomic<float *> g_scratch_ptr[kMaxDevices];
+
+// Device address of `scratch` on the current device, resolved once per device (with that device
+// current, as it is for the caller's launch).
+static int scratch_on_current_device(float **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDevices) {
+        g_err = "vfa_mha_fwd_kvcache_noalloc: device index beyond the per-device scratch table";
+        return VFA_ERR_UNSUPPORTED;
+    }
+    float *ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(scratch)");
+        if (!ptr) {
+            g_err = "hipGetSymbolAddress(scratch) returned a null address";
+            return VFA_ERR_HIP;
+        }
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    *out = ptr;
+    return VFA_OK;
+}
+
+static size_t split_scratch_floats(const vfa_params *p, int splits, size_t *lse_floats) {
+    const size_t rows = (size_t)p->b * (size_t)p->h * (size_t)p->seqlen_q;
+    const size_t lse = ((size_t)splits * rows + 63) / 64 * 64;  // keeps the O partials 256-byte aligned
+    if (lse_floats) *lse_floats = lse;
+    return lse + (size_t)splits * rows * (size_t)p->d;
+}
+
+extern "C" int vfa_mha_fwd_kvcache_noalloc(const vfa_params *p) {
+    g_err.clear();
+    int rc = common_checks(p);
+    if (rc) return rc;
+    VFA_CHECK(p->seqlen_q > 0, "seqlen_q must be positive");
+    vfa_params q = *p;
+    q.oaccum = nullptr;
+    q.softmax_lseaccum = nullptr;
+    constexpr size_t cap = VFA_NOALLOC_SCRATCH_BYTES / sizeof(float);
+    if (q.num_splits == 0) {
+        // the count the allocating path's caller would pick (set_params_splitkv), lowered until the
+        // partial results fit the static array
+        q.num_splits = vfa_splitkv_num_splits(p->b, p->h, p->d, p->seqlen_k, p->seqlen_q, num_cus());
+        while (q.num_splits > 1 && split_scratch_floats(p, q.num_splits, nullptr) > cap) q.num_splits--;
+    }
+    if (q.num_splits > 1) {
+        VFA_CHECK(q.num_splits <= 128, "num_splits > 128 not supported");
+        size_t lse_floats = 0;
+        const size_t need = split_scratch_floats(p, q.num_splits, &lse_floats);
+        if (need > cap) {
+            g_err = "vfa_mha_fwd_kvcache_noalloc: num_splits * b * h * seqlen_q * (d + 1) floats = " +
+                    std::to_string(need * sizeof(float)) + " bytes exceed the static scratch of " +
+                    std::to_string((size_t)VFA_NOALLOC_SCRATCH_BYTES) +
+                    " bytes; lower num_splits or call vfa_mha_fwd_kvcache with caller-provided scratch";
+            return VFA_ERR_INVALID;
+        }
+        float *ptr = nullptr;
+        if ((rc = scratch_on_current_device(&ptr))) return rc;
+        // Every split of every row is written by the kernels before the combine kernel reads it
+        // (empty splits store 0 / -inf), so nothing has to start at zero; the previous call's
+        // contents are simply overwritten.  Two calls that overlap on one GPU would race here.
+        q.softmax_lseaccum = ptr;
+        q.oaccum = ptr + lse_floats;
+    }
+    return vfa_mha_fwd_kvcache(&q);
 }
 
 extern "C" size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_0) {
