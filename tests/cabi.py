@@ -52,25 +52,31 @@ NOALLOC_SCRATCH_BYTES = 32 << 20   # VFA_NOALLOC_SCRATCH_BYTES of include/vfa.h
 _lib = None
 
 
+def load(path):
+    """Loads one build of the library and declares its entry points."""
+    import torch  # noqa: F401  (first, so that both use the HIP runtime torch ships)
+    h = C.CDLL(path)
+    for name in ENTRY_POINTS:
+        fn = getattr(h, name)
+        fn.argtypes = [C.POINTER(VfaParams)]
+        fn.restype = _int
+    h.vfa_last_error.restype = C.c_char_p
+    h.vfa_version.restype = C.c_char_p
+    h.vfa_params_sizeof.restype = C.c_size_t
+    h.vfa_num_splits_heuristic.argtypes = [_int] * 4
+    h.vfa_splitkv_num_splits.argtypes = [_int] * 6
+    h.vfa_bwd_dq_accum_elems.argtypes = [_int] * 5
+    h.vfa_bwd_dq_accum_elems.restype = C.c_size_t
+    h.vfa_bwd_head_splits.argtypes = [_int] * 5
+    assert h.vfa_params_sizeof() == C.sizeof(VfaParams), "ctypes mirror of vfa_params is stale"
+    return h
+
+
 def lib():
-    """Loads libvfa_hip.so (after torch, so that both use the HIP runtime torch ships)."""
+    """libvfa_hip.so, loaded once."""
     global _lib
     if _lib is None:
-        import torch  # noqa: F401
-        _lib = C.CDLL(LIB_PATH)
-        for name in ENTRY_POINTS:
-            fn = getattr(_lib, name)
-            fn.argtypes = [C.POINTER(VfaParams)]
-            fn.restype = _int
-        _lib.vfa_last_error.restype = C.c_char_p
-        _lib.vfa_version.restype = C.c_char_p
-        _lib.vfa_params_sizeof.restype = C.c_size_t
-        _lib.vfa_num_splits_heuristic.argtypes = [_int] * 4
-        _lib.vfa_splitkv_num_splits.argtypes = [_int] * 6
-        _lib.vfa_bwd_dq_accum_elems.argtypes = [_int] * 5
-        _lib.vfa_bwd_dq_accum_elems.restype = C.c_size_t
-        _lib.vfa_bwd_head_splits.argtypes = [_int] * 5
-        assert _lib.vfa_params_sizeof() == C.sizeof(VfaParams), "ctypes mirror of vfa_params is stale"
+        _lib = load(LIB_PATH)
     return _lib
 
 

@@ -339,6 +339,69 @@ def test_decode_config5_shape_properties():
     assert np.abs(f(o1) - ro).max() <= ulp_tol("fp16", ro)
 
 
+def test_decode_config5_full_batch():
+    """The decode configuration at its full per-GPU size (b128 sq1 kv8192 h32/hk8 d128 fp16, 4.3 GB
+    of K+V), checked through properties that do not need a CPU pass over the whole batch: a
+    sequence computed alone equals its row of the batched call bit for bit, a paged cache in random
+    page order equals the contiguous one bit for bit, ragged cache_seqlens rows equal the same rows
+    computed alone, V = 1 gives 1, and the first / last / a ragged entry agree with the oracle."""
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    import vllm_flash_attn as fa
+    torch.manual_seed(5)
+    b, sk, h, hk, d = 128, 8192, 32, 8, 128
+    q = torch.randn(b, 1, h, d, device="cuda", dtype=torch.float16)
+    kc = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.float16)
+    vc = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.float16)
+    full = torch.full((b,), sk, dtype=torch.int32, device="cuda")
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    ragged = torch.randint(1, sk + 1, (b,), generator=gen, dtype=torch.int32)
+    ragged[3], ragged[77] = 1, sk - 1
+    ragged = ragged.cuda()
+
+    def alone(i, lens):
+        return fa.flash_attn_with_kvcache(q[i:i + 1], kc[i:i + 1], vc[i:i + 1], cache_seqlens=lens[i:i + 1],
+                                          causal=True, num_splits=1)
+
+    def check_oracle(o, i, lens):
+        f = lambda t: t[i:i + 1].float().cpu().numpy()
+        ro, _ = fa_oracle.attention_fwd(f(q), f(kc), f(vc), dtype="fp16",
+                                        cache_seqlens=lens[i:i + 1].cpu().numpy(), causal=True)
+        assert np.abs(f(o) - ro).max() <= ulp_tol("fp16", ro)
+
+    o_full = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=full, causal=True, num_splits=1)
+    assert torch.isfinite(o_full).all()
+    for i in (0, 63, 127):
+        assert torch.equal(o_full[i:i + 1], alone(i, full))
+    check_oracle(o_full, 0, full)
+    check_oracle(o_full, 127, full)
+    # the library's own split count (what the reference's caller gets with num_splits = 0)
+    o_auto = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=full, causal=True)
+    assert (o_auto.float() - o_full.float()).abs().max().item() <= 2 * 2.0 ** -11
+
+    o_rag = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=ragged, causal=True, num_splits=1)
+    assert torch.isfinite(o_rag).all()
+    for i in (3, 77, 100):
+        assert torch.equal(o_rag[i:i + 1], alone(i, ragged))
+    check_oracle(o_rag, 3, ragged)
+    check_oracle(o_rag, 100, ragged)
+
+    o_one = fa.flash_attn_with_kvcache(q, kc, torch.ones_like(vc), cache_seqlens=ragged, causal=True, num_splits=1)
+    assert (o_one.float() - 1.0).abs().max().item() <= 2.0 ** -10
+    del o_one
+
+    page = 16
+    nb = b * sk // page
+    perm = torch.randperm(nb, device="cuda")
+    bt = perm.view(b, sk // page).to(torch.int32)
+    kp = torch.empty(nb, page, hk, d, device="cuda", dtype=torch.float16)
+    vp = torch.empty_like(kp)
+    kp[perm] = kc.view(nb, page, hk, d)
+    vp[perm] = vc.view(nb, page, hk, d)
+    o_paged = fa.flash_attn_with_kvcache(q, kp, vp, cache_seqlens=ragged, block_table=bt, causal=True, num_splits=1)
+    assert torch.equal(o_paged, o_rag)
+
+
 def test_error_messages_match_reference():
     import vllm_flash_attn as fa
     q = torch.randn(1, 8, 4, 64, device="cuda", dtype=torch.float32)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Interleaved timing, in one process, of the forward kernel from several builds of the library on
+random and on all-zero inputs (development tool):  ab_fwd.py lib1.so lib2.so ..."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import ctypes as C
+import torch
+import cabi
+import bench
+
+SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 8192, 32, 8, 128, True)]
+
+
+def main():
+    libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+    hip = bench.Hip()
+    handles = [cabi.load(os.path.abspath(p)) for p in libs]
+    stream = torch.cuda.current_stream().cuda_stream
+    for b, s, h, hk, d, causal in SHAPES:
+        for data in ("random", "zeros"):
+            torch.manual_seed(0)
+            mk = torch.randn if data == "random" else torch.zeros
+            q = mk(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+            k = mk(b, s, hk, d, device="cuda", dtype=torch.bfloat16)
+            v = mk(b, s, hk, d, device="cuda", dtype=torch.bfloat16)
+            out = torch.empty_like(q)
+            lse = torch.empty(b, h, s, device="cuda", dtype=torch.float32)
+            P = bench.build_params(cabi, q, k, v, out, lse, causal, stream)
+            times = [[] for _ in handles]
+            for rnd in range(14):
+                for i, hd in enumerate(handles):
+                    e0, e1 = hip.event(), hip.event()
+                    hip.record(e0, stream)
+                    assert hd.vfa_mha_fwd(C.byref(P)) == 0
+                    hip.record(e1, stream)
+                    torch.cuda.synchronize()
+                    if rnd >= 4:
+                        times[i].append(hip.elapsed_ms(e0, e1))
+            flops = 4.0 * b * h * s * s * d * (0.5 if causal else 1.0)
+            for i, p in enumerate(libs):
+                t = sorted(times[i])[len(times[i]) // 2]
+                print(f"b{b} s{s} h{h}/{hk} causal={causal} {data:6s} {os.path.basename(p):26s} {t:.3f} ms {flops / t / 1e9:.0f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()

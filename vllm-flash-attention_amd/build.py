@@ -82,6 +82,26 @@ def build_stamp():
     return out
 
 
+def build_variant(name, defines, sources):
+    """Development builds for A/B timing: build/libvfa_<name>.so with `defines` (-D...) applied to
+    `sources`, every other object taken from the main build (never loaded by the product)."""
+    build_hip()
+    od = os.path.join(OBJ, "variant_" + name)
+    os.makedirs(od, exist_ok=True)
+    objs = []
+    for src in HIP_SOURCES:
+        if src in sources:
+            o = os.path.join(od, src.replace(".hip", ".o"))
+            subprocess.check_call([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) +
+                                  ["-c", os.path.join(CSRC, src), "-o", o])
+        else:
+            o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+    out = os.path.join(OBJ, "libvfa_%s.so" % name)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def torch_ext_path():
     suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
     return os.path.join(HERE, "vllm_flash_attn_2_cuda" + suffix)

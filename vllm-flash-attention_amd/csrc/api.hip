@@ -69,16 +69,7 @@ static int check_arch() {
     return VFA_OK;
 }
 
-static int num_cus() {
-    static thread_local int cached_dev = -1, cus = 256;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        cached_dev = dev;
-    }
-    return cus;
-}
+static int num_cus() { return vfa::device_num_cus(); }
 
 // Checks shared by the three forward entry points (flash_api.cpp:262-287 and siblings).
 static int common_checks(const vfa_params *p) {
@@ -133,6 +124,7 @@ static void fill_common(const vfa_params *p, KParams &k, int seqlen_q_for_fold, 
     if (wl >= 0 && wr < 0) wr = seqlen_k_for_fold;
     k.wl = wl; k.wr = wr;
     k.is_local = (wl >= 0 || wr >= 0) && !k.is_causal;
+    k.dbg_flags = vfa::g_tuning[2];
     k.num_splits = 1;
     // flash_api.cpp:105-113: keep probability, its 8-bit threshold (rounded down: the test is <=)
     k.p_keep = 1.f - p->p_dropout;

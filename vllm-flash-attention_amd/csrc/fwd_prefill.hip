@@ -19,6 +19,35 @@
 
 namespace vfa {
 
+#ifdef MFMA16_PROBE
+// Timing probe only (results are wrong): the work of one 32x32x16 MFMA issued as two 16x16x32 MFMAs
+// on the same operand registers -- same cycles, operand reads and accumulator registers, so that
+// the clock the chip holds on the other MFMA shape can be measured before a kernel is rewritten.
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+template <bool BF16>
+__device__ __forceinline__ f32x16 mma_probe(i32x4 a, i32x4 b0, i32x4 b1, f32x16 c, const int par) {
+    f32x4p c0, c1;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { c0[t] = c[4 * par + t]; c1[t] = c[8 + 4 * par + t]; }
+    if constexpr (BF16) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1), c1, 0, 0, 0);
+    } else {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b0), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b1), c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) { c[4 * par + t] = c0[t]; c[8 + 4 * par + t] = c1[t]; }
+    return c;
+}
+#define MMA_S(kf, ks, acc) mma_probe<BF16>(kf, qf[(ks) & ~1], qf[(ks) | 1], (ks) < 2 ? zero : acc, (ks) & 1)
+#define MMA_O(vf, ks, acc) mma_probe<BF16>(vf, pf[(ks) & ~1], pf[(ks) | 1], acc, (ks) & 1)
+#else
+#define MMA_S(kf, ks, acc) mma32<BF16>(kf, qf[ks], (ks) == 0 ? zero : acc)
+#define MMA_O(vf, ks, acc) mma32<BF16>(vf, pf[ks], acc)
+#endif
+
+
 #if defined(VFA_STAMP) && defined(VFA_DROPOUT_TU)
 #undef VFA_STAMP
 #endif
@@ -453,7 +482,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks]);
-            s[0] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[0]);
+            s[0] = MMA_S(kf, ks, s[0]);
         }
         constexpr bool SPEC = DP >= 128 && !DROP;  // measured: +1..2 % at d = 128, -2.5 % at d = 64
         const float mc_old = (m_run == -INFINITY ? 0.f : m_run) * c2;
@@ -462,7 +491,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks] + 32 * ROWB);
-                s[1] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[1]);
+                s[1] = MMA_S(kf, ks, s[1]);
             }
         } else {
             // second 32 keys: MFMA ks, then a slice of the vector work on the first 32 keys, fenced
@@ -473,7 +502,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 if (ks + 2 < KS) kf2[(ks + 2) % 3] = *(const i32x4 *)(kb + k_rd[ks + 2] + 32 * ROWB);
-                s[1] = mma32<BF16>(kf2[ks % 3], qf[ks], ks == 0 ? zero : s[1]);
+                s[1] = MMA_S(kf2[ks % 3], ks, s[1]);
                 if constexpr (!SPEC) continue;
 #pragma unroll
                 for (int j = ks * 16 / KS; j < (ks + 1) * 16 / KS; j++) mx = fmaxf(mx, s[0][j]);
@@ -620,7 +649,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 i32x4 vf;
                 const i32x2 a0 = __builtin_bit_cast(i32x2, v0), a1 = __builtin_bit_cast(i32x2, v1);
                 vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a1[0]; vf[3] = a1[1];
-                o[db] = mma32<BF16>(vf, pf[ks], o[db]);
+                o[db] = MMA_O(vf, ks, o[db]);
             }
         }
         l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);

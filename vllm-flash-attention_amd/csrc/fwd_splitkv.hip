@@ -64,31 +64,50 @@ __device__ __forceinline__ i32x4 rotary_chunk(const unsigned short *src, int d0,
 template <int DP>
 struct DecodeCfg {
     static constexpr int CPR = DP / 8;
+    // Above d = 128 a tile's staging registers (256 bytes of K and of V per thread at 256 threads)
+    // plus the O accumulators no longer fit 256 registers and the kernel spilled to scratch (2.6
+    // instead of 5 TB/s).  There the workgroup has 8 waves: wave w and wave w + 4 take the same 32
+    // keys, both compute their scores (duplicated MFMAs cost nothing on an HBM-bound kernel), and
+    // each accumulates one half of the head dim of O; every thread stages half as many bytes.
+    static constexpr int DSPLIT = DP > 128 ? 2 : 1;
+    static constexpr int NT = DEC_NT * DSPLIT;
     static constexpr int TILE_CHUNKS = DEC_BN * CPR;
-    static constexpr int CH = TILE_CHUNKS / DEC_NT;
+    static constexpr int CH = TILE_CHUNKS / NT;
     static constexpr int TILE_BYTES = DEC_BN * DP * 2;
     static constexpr int KV_LDS = 2 * TILE_BYTES;
     static constexpr int O_ROWB = DP * 4 + 16;
     static constexpr int O_LDS = DEC_NW * DEC_BM * O_ROWB + DEC_NW * DEC_BM * 8;
-    static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+    // above d = 128 the query fragments are re-read from LDS every tile instead of held in 64 registers
+    static constexpr int Q_LDS = DP > 128 ? DEC_BM * DP * 2 : 0;
+    static constexpr int LDS_BYTES = KV_LDS + Q_LDS > O_LDS ? KV_LDS + Q_LDS : O_LDS;
 };
 
 template <int DP, bool BF16>
-__global__ void __launch_bounds__(DEC_NT, DP == 256 ? 1 : 2)
+__global__ void __launch_bounds__(DecodeCfg<DP>::NT, DP == 256 ? 1 : 2)
 fwd_decode_kernel(const KParams p, const int n_mblocks) {
     using Cfg = DecodeCfg<DP>;
-    constexpr int CPR = Cfg::CPR, CH = Cfg::CH;
-    constexpr int KS = DP / 16, NDB = DP / 32;
+    constexpr int CPR = Cfg::CPR, CH = Cfg::CH, NT = Cfg::NT;
+    constexpr int KS = DP / 16, NDB = DP / 32 / Cfg::DSPLIT;  // NDB: 32-wide blocks of O this wave accumulates
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & (DEC_NW - 1);   // which 32 keys of the staged tile
+    const int dhalf = wave_id / DEC_NW;        // which part of the head dim of O (0 unless DSPLIT = 2)
     const int r = lane & 31, hh = lane >> 5;
 
-    // block -> (split, batch, head, m_block); consecutive blocks walk the heads of one batch so
-    // that the query heads of a KV group (same K/V bytes) are co-scheduled.
+    // block -> (split, batch, head, m_block); consecutive blocks walk the heads of one batch.
+    // Hardware deals consecutive block ids round-robin over the 8 XCDs.  With one split that puts
+    // head x of every batch entry on XCD x, which measured best (b128 kv8192 hk8: 747 us).  With
+    // several splits the ids are regrouped so that each XCD owns one contiguous range of the index,
+    // i.e. all heads and splits of a batch entry run on one XCD at about the same time: 727 us
+    // against 801 us ungrouped at 4 splits, 737 against 783 at 2.
     int L = blockIdx.x;
+    if ((p.num_splits > 1) != ((p.dbg_flags & 1) != 0)) {
+        const int per_xcd = gridDim.x / 8;
+        if (L < per_xcd * 8) L = (L % 8) * per_xcd + L / 8;
+    }
     const int m_block = L % n_mblocks; L /= n_mblocks;
     const int bidh = L % p.h; L /= p.h;
     const int split = L % p.num_splits; L /= p.num_splits;
@@ -121,7 +140,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 
     if (n_max <= n_min) {
         // flash_fwd_kernel.h:513-552: O = 0 and LSE = -inf (split) / +inf (final)
-        for (int c = tid; c < DEC_BM * CPR; c += DEC_NT) {
+        for (int c = tid; c < DEC_BM * CPR; c += NT) {
             const int row = q0 + c / CPR, ch = c % CPR;
             if (row < sq && ch * 8 < p.d) {
                 if (is_split) {
@@ -133,7 +152,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
                 }
             }
         }
-        for (int c = tid; c < DEC_BM; c += DEC_NT)
+        for (int c = tid; c < DEC_BM; c += NT)
             if (q0 + c < sq) lse_g[q0 + c] = is_split ? -INFINITY : INFINITY;
         return;
     }
@@ -158,7 +177,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         if (!bt) return;
 #pragma unroll
         for (int i = 0; i < CH; i++) {
-            const int grow = n * DEC_BN + (tid + i * DEC_NT) / CPR;
+            const int grow = n * DEC_BN + (tid + i * NT) / CPR;
             const int safe = grow < sk ? grow : 0;
             pg[i] = bt[p.page_shift >= 0 ? safe >> p.page_shift : safe / p.page_size];
         }
@@ -166,7 +185,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     auto load_tile = [&](int n) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
-            const int c = tid + i * DEC_NT;
+            const int c = tid + i * NT;
             const int row = c / CPR, ch = c % CPR;
             const int grow = n * DEC_BN + row;
             const bool ok = grow < sk && ch * 8 < p.d;
@@ -187,7 +206,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
-            const int c = tid + i * DEC_NT;
+            const int c = tid + i * NT;
             const int row = c / CPR, ch = c % CPR;
             const int off = lds_off<DP>(row, ch);
             *(i32x4 *)(smem + off) = kreg[i];
@@ -221,6 +240,15 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
                     qf[s] = rotary_chunk<BF16>(qr, col, cosp, sinp, p.rotary_dim, p.rotary_interleaved);
             }
         }
+    }
+
+    char *q_lds = smem + Cfg::KV_LDS;  // fragment s of lane l at (s * 64 + l) * 16
+    if constexpr (Cfg::Q_LDS > 0) {
+        if (wave_id == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; s++) *(i32x4 *)(q_lds + (s * 64 + lane) * 16) = qf[s];
+        }
+        // (the first tile's barrier below orders these stores before any wave reads them)
     }
 
     f32x16 o[NDB];
@@ -257,7 +285,8 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const i32x4 kf = *(const i32x4 *)(kb + lds_off<DP>(wrow + r, 2 * ks + hh));
-            s = mma32<BF16>(kf, qf[ks], s);
+            if constexpr (Cfg::Q_LDS > 0) s = mma32<BF16>(kf, *(const i32x4 *)(q_lds + (ks * 64 + lane) * 16), s);
+            else s = mma32<BF16>(kf, qf[ks], s);
         }
 
         const int c0 = n * DEC_BN + wrow;
@@ -315,7 +344,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const int row0 = wrow + 16 * ks + 4 * hh + tr_q;
-                const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
+                const int ch = 4 * (db + dhalf * NDB) + 2 * tr_g + (tr_p >> 1);
                 const s16x4 v0 = lds_read_tr16(vb + lds_off<DP>(row0, ch) + 8 * (tr_p & 1));
                 const s16x4 v1 = lds_read_tr16(vb + lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1));
                 i32x4 vf;
@@ -330,7 +359,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     // ---- merge the four waves' partial states (same algebra as the split combine) ----
     float *ml = (float *)(smem + DEC_NW * DEC_BM * Cfg::O_ROWB);  // [wave][row][2]
     const float l_w = half_swap_sum(l_run);
-    if (hh == 0) {
+    if (hh == 0 && dhalf == 0) {
         ml[(wave * DEC_BM + r) * 2 + 0] = m_run;
         ml[(wave * DEC_BM + r) * 2 + 1] = l_w;
     }
@@ -356,15 +385,15 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             f32x4 w4;
 #pragma unroll
             for (int t = 0; t < 4; t++) w4[t] = o[db][4 * g4 + t] * f;
-            *(f32x4 *)(ob + r * Cfg::O_ROWB + (32 * db + 8 * g4 + 4 * hh) * 4) = w4;
+            *(f32x4 *)(ob + r * Cfg::O_ROWB + (32 * (db + dhalf * NDB) + 8 * g4 + 4 * hh) * 4) = w4;
         }
-    if (wave == 0 && hh == 0 && q0 + r < sq) {
+    if (wave_id == 0 && hh == 0 && q0 + r < sq) {
         // softmax.h:179: LSE = max*scale + log(sum); empty -> +inf (final) / -inf (split partial)
         lse_g[q0 + r] = bad ? (is_split ? -INFINITY : INFINITY) : m_all * p.scale + __logf(l_all);
     }
     __syncthreads();
     // each thread sums 8 consecutive d of one row over the waves
-    for (int c = tid; c < DEC_BM * CPR; c += DEC_NT) {
+    for (int c = tid; c < DEC_BM * CPR; c += NT) {
         const int row = c / CPR, ch = c % CPR;
         f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
@@ -490,6 +519,70 @@ append_kv_kernel(const KParams p) {
     *(i32x4 *)(kd + d0) = rotary_chunk<BF16>(ks, d0, cosp, sinp, p.rotary_dim, p.rotary_interleaved);
 }
 
+// The same merge for few splits (<= 16): one thread per 16-byte output chunk, looping over the
+// splits itself -- with so few terms the loop is short and its loads are independent, and the grid
+// is rows * d / 8 threads instead of one 256-thread workgroup (two barriers, mostly idle lanes) per
+// row.  Sums run in split order, like the kernel above with a single split lane.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+fwd_combine_flat_kernel(const KParams p) {
+    const int cpr = p.d / 8;
+    const int64_t total_rows = (int64_t)p.b * p.h * p.seqlen_q;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_rows * cpr) return;
+    const int64_t row = idx / cpr;
+    const int ch = (int)(idx % cpr);
+    const int sqi = (int)(row % p.seqlen_q);
+    const int bh = (int)(row / p.seqlen_q);
+    const int bidb = bh / p.h, bidh = bh % p.h;
+    const BlockInfo bi(p, bidb);
+    if (sqi >= bi.sq) return;
+    float ls[16];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        ls[s] = s < p.num_splits ? p.lseaccum[s * total_rows + row] : -INFINITY;
+        lmax = fmaxf(lmax, ls[s]);
+    }
+    if (lmax == -INFINITY) lmax = 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; s++)
+        if (s < p.num_splits) lsum += expf(ls[s] - lmax);
+    const float lse = (lsum == 0.f || lsum != lsum) ? INFINITY : logf(lsum) + lmax;
+    if (ch == 0) p.lse[row] = lse;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        if (s < p.num_splits) {
+            const float w = expf(ls[s] - lse);
+            const float *src = p.oaccum + (s * total_rows + row) * p.d + ch * 8;
+            a0 += *(const f32x4 *)src * w;
+            a1 += *(const f32x4 *)(src + 4) * w;
+        }
+    }
+    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
+                         (int64_t)bidh * p.o_hs + (int64_t)sqi * p.o_rs + ch * 8;
+    i32x4 w;
+    w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
+    w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
+    *(i32x4 *)og = w;
+}
+
+static hipError_t launch_combine(const KParams &p, hipStream_t stream) {
+    const long long rows = (long long)p.b * p.h * p.seqlen_q;
+    if (rows == 0) return hipSuccess;
+    if (p.num_splits <= 16) {
+        const unsigned blocks = (unsigned)((rows * (p.d / 8) + 255) / 256);
+        if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_flat_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(fwd_combine_flat_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+    } else {
+        if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_kernel<true>, dim3((unsigned)rows), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(fwd_combine_kernel<false>, dim3((unsigned)rows), dim3(256), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
 template <int DP, bool BF16>
 static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
     using Cfg = DecodeCfg<DP>;
@@ -499,27 +592,17 @@ static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
     auto kern = fwd_decode_kernel<DP, BF16>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(DEC_NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
-    hipError_t e = hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
+    hipError_t e;
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (p.num_splits > 1) {
-        const unsigned cblocks = (unsigned)((long long)p.b * p.h * p.seqlen_q);
-        if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_kernel<true>, dim3(cblocks), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL(fwd_combine_kernel<false>, dim3(cblocks), dim3(256), 0, stream, p);
-        e = hipGetLastError();
-    }
+    if (p.num_splits > 1) e = launch_combine(p, stream);
     return e;
 }
 
 // The merge alone, for split partial results written by another kernel (the prefill kernel's
 // split variants).
-hipError_t run_fwd_combine(const KParams &p, hipStream_t stream) {
-    const unsigned cblocks = (unsigned)((long long)p.b * p.h * p.seqlen_q);
-    if (cblocks == 0) return hipSuccess;
-    if (p.is_bf16) hipLaunchKernelGGL(fwd_combine_kernel<true>, dim3(cblocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(fwd_combine_kernel<false>, dim3(cblocks), dim3(256), 0, stream, p);
-    return hipGetLastError();
-}
+hipError_t run_fwd_combine(const KParams &p, hipStream_t stream) { return launch_combine(p, stream); }
 
 hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;

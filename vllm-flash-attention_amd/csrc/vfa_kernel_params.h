@@ -12,7 +12,20 @@ namespace vfa {
 // Development switches (kernel-variant selection for A/B timing inside one process), set through
 // vfa_debug_set_tuning(); all zero = the shipped choices.
 //   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one
+//   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs
 extern int g_tuning[8];
+
+// Compute units of the current device (cached per thread and device).
+inline int device_num_cus() {
+    static thread_local int cached_dev = -1, cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        cached_dev = dev;
+    }
+    return cus;
+}
 
 // Host side: kernels that need more than 64 KiB of dynamic LDS must be told so once per device.
 // `done` is a per-instantiation bit set of the devices already configured (function-local static
@@ -38,6 +51,7 @@ struct KParams {
     int64_t v_bs, v_rs, v_hs;
     int64_t o_bs, o_rs, o_hs;
     int b, h, h_k, h_ratio, d;
+    int dbg_flags;
     int seqlen_q, seqlen_k;     // max query length, max key length / cache capacity
     const int *cu_seqlens_q;    // b+1 or null
     const int *cu_seqlens_k;    // b+1 cumulative, or b lengths when !k_cumulative, or null
