@@ -61,32 +61,46 @@ __device__ __forceinline__ i32x4 rotary_chunk(const unsigned short *src, int d0,
     return w;
 }
 
-template <int DP>
+// Geometry of the decode kernel.  The basic workgroup is 4 waves that split the 128 keys of a staged
+// tile between them.  Two cases double it to 8 waves (two groups of 4, one workgroup per CU):
+//   * d > 128 (DSPLIT = 2): a tile's staging registers (256 bytes of K and of V per thread at 256
+//     threads) plus the O accumulators do not fit 256 registers -- the kernel spilled to scratch and
+//     ran at 2.6 TB/s.  Group g takes half g of the head dim of O; both groups compute the scores
+//     of their 32 keys (duplicated MFMAs cost nothing on an HBM-bound kernel); every thread stages
+//     half as many bytes; the query fragments are re-read from LDS instead of held in 64 registers.
+//     d = 256 then reads K+V at 6.0-6.26 TB/s.
+//   * HPB = 2 heads per workgroup at d = 128: group g takes head 2 j + g.  In the (batch, key, head,
+//     d) layout the rows of adjacent heads are adjacent in memory, so the workgroup reads 512
+//     contiguous bytes per key instead of 256.  b128 kv8192 hk8 d128: 5.71 -> 6.17 TB/s (a
+//     read-only probe of 256-byte pieces at a 2 KiB stride against one contiguous stream per
+//     workgroup shows 3 % in favour of longer pieces).  Four heads per workgroup at d = 64 (16
+//     waves, 128 registers each) spilled and ran at half the rate of one head per workgroup.
+template <int DP, int HPB>
 struct DecodeCfg {
-    static constexpr int CPR = DP / 8;
-    // Above d = 128 a tile's staging registers (256 bytes of K and of V per thread at 256 threads)
-    // plus the O accumulators no longer fit 256 registers and the kernel spilled to scratch (2.6
-    // instead of 5 TB/s).  There the workgroup has 8 waves: wave w and wave w + 4 take the same 32
-    // keys, both compute their scores (duplicated MFMAs cost nothing on an HBM-bound kernel), and
-    // each accumulates one half of the head dim of O; every thread stages half as many bytes.
+    static constexpr int CPR = DP / 8;         // 16-byte chunks of one head's row
     static constexpr int DSPLIT = DP > 128 ? 2 : 1;
-    static constexpr int NT = DEC_NT * DSPLIT;
-    static constexpr int TILE_CHUNKS = DEC_BN * CPR;
+    static constexpr int NGRP = DSPLIT * HPB;  // groups of DEC_NW waves
+    static_assert(NGRP <= 2, "at most two groups of waves");
+    static constexpr int NT = DEC_NT * NGRP;
+    static constexpr int ROWE = DP * HPB;      // elements of one staged row (all heads of the workgroup)
+    static constexpr int CPRR = ROWE / 8;
+    static constexpr int TILE_CHUNKS = DEC_BN * CPRR;
     static constexpr int CH = TILE_CHUNKS / NT;
-    static constexpr int TILE_BYTES = DEC_BN * DP * 2;
+    static constexpr int TILE_BYTES = DEC_BN * ROWE * 2;
     static constexpr int KV_LDS = 2 * TILE_BYTES;
     static constexpr int O_ROWB = DP * 4 + 16;
-    static constexpr int O_LDS = DEC_NW * DEC_BM * O_ROWB + DEC_NW * DEC_BM * 8;
-    // above d = 128 the query fragments are re-read from LDS every tile instead of held in 64 registers
+    static constexpr int O_HEAD = DEC_NW * DEC_BM * O_ROWB + DEC_NW * DEC_BM * 8;  // merge area of one head
+    static constexpr int O_LDS = HPB * O_HEAD;
     static constexpr int Q_LDS = DP > 128 ? DEC_BM * DP * 2 : 0;
     static constexpr int LDS_BYTES = KV_LDS + Q_LDS > O_LDS ? KV_LDS + Q_LDS : O_LDS;
+    static constexpr int MIN_WG = NGRP >= 2 ? 1 : 2;
 };
 
-template <int DP, bool BF16>
-__global__ void __launch_bounds__(DecodeCfg<DP>::NT, DP == 256 ? 1 : 2)
+template <int DP, bool BF16, int HPB>
+__global__ void __launch_bounds__((DecodeCfg<DP, HPB>::NT), (DecodeCfg<DP, HPB>::MIN_WG))
 fwd_decode_kernel(const KParams p, const int n_mblocks) {
-    using Cfg = DecodeCfg<DP>;
-    constexpr int CPR = Cfg::CPR, CH = Cfg::CH, NT = Cfg::NT;
+    using Cfg = DecodeCfg<DP, HPB>;
+    constexpr int CPR = Cfg::CPR, CPRR = Cfg::CPRR, CH = Cfg::CH, NT = Cfg::NT, ROWE = Cfg::ROWE;
     constexpr int KS = DP / 16, NDB = DP / 32 / Cfg::DSPLIT;  // NDB: 32-wide blocks of O this wave accumulates
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -94,10 +108,12 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_id & (DEC_NW - 1);   // which 32 keys of the staged tile
-    const int dhalf = wave_id / DEC_NW;        // which part of the head dim of O (0 unless DSPLIT = 2)
+    const int grp = wave_id / DEC_NW;          // group of waves
+    const int dhalf = Cfg::DSPLIT == 2 ? grp : 0;  // which part of the head dim of O
+    const int hsel = HPB > 1 ? grp : 0;            // which head of the workgroup
     const int r = lane & 31, hh = lane >> 5;
 
-    // block -> (split, batch, head, m_block); consecutive blocks walk the heads of one batch.
+    // block -> (split, batch, head block, m_block); consecutive blocks walk the heads of one batch.
     // Hardware deals consecutive block ids round-robin over the 8 XCDs.  With one split that puts
     // head x of every batch entry on XCD x, which measured best (b128 kv8192 hk8: 747 us).  With
     // several splits the ids are regrouped so that each XCD owns one contiguous range of the index,
@@ -108,11 +124,13 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         const int per_xcd = gridDim.x / 8;
         if (L < per_xcd * 8) L = (L % 8) * per_xcd + L / 8;
     }
+    const int n_hblocks = p.h / HPB;
     const int m_block = L % n_mblocks; L /= n_mblocks;
-    const int bidh = L % p.h; L /= p.h;
+    const int bidh0 = (L % n_hblocks) * HPB; L /= n_hblocks;
     const int split = L % p.num_splits; L /= p.num_splits;
     const int bidb = L;
-    const int hk = bidh / p.h_ratio;
+    const int bidh = bidh0 + hsel;         // this wave's query head
+    const int hk0 = bidh0 / p.h_ratio;     // first KV head of the workgroup (HPB = 2 only runs with h == h_k)
     const bool is_split = p.num_splits > 1;
 
     const BlockInfo bi(p, bidb);
@@ -137,10 +155,13 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     float *lse_g = is_split ? p.lseaccum + acc_row0
                             : p.lse + ((int64_t)bidb * p.h + bidh) * p.seqlen_q;
     float *oacc_g = is_split ? p.oaccum + acc_row0 * p.d : nullptr;
+    // threads that share this wave's head: the whole workgroup, or its group of 4 waves
+    const int tid_h = HPB > 1 ? (tid & (DEC_NT - 1)) : tid;
+    constexpr int NT_H = HPB > 1 ? DEC_NT : NT;
 
     if (n_max <= n_min) {
         // flash_fwd_kernel.h:513-552: O = 0 and LSE = -inf (split) / +inf (final)
-        for (int c = tid; c < DEC_BM * CPR; c += NT) {
+        for (int c = tid_h; c < DEC_BM * CPR; c += NT_H) {
             const int row = q0 + c / CPR, ch = c % CPR;
             if (row < sq && ch * 8 < p.d) {
                 if (is_split) {
@@ -152,14 +173,14 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
                 }
             }
         }
-        for (int c = tid; c < DEC_BM; c += NT)
+        for (int c = tid_h; c < DEC_BM; c += NT_H)
             if (q0 + c < sq) lse_g[q0 + c] = is_split ? -INFINITY : INFINITY;
         return;
     }
 
     const int bidb_cache = p.cache_batch_idx ? p.cache_batch_idx[bidb] : bidb;
-    const unsigned short *kg = (const unsigned short *)p.k + (int64_t)hk * p.k_hs;
-    const unsigned short *vg = (const unsigned short *)p.v + (int64_t)hk * p.v_hs;
+    const unsigned short *kg = (const unsigned short *)p.k + (int64_t)hk0 * p.k_hs;
+    const unsigned short *vg = (const unsigned short *)p.v + (int64_t)hk0 * p.v_hs;
     const int *bt = nullptr;
     if (p.block_table) {
         bt = p.block_table + (int64_t)bidb * p.bt_bs;
@@ -168,6 +189,9 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         vg += bi.k_off(p.v_bs, p.v_rs, bidb_cache);
     }
 
+    // chunk c of the tile: key c / CPRR, and within the staged row head (c % CPRR) / CPR, 16-byte
+    // piece (c % CPRR) % CPR -- consecutive threads read consecutive 16 bytes of a head's row and
+    // then of the next head's
     i32x4 kreg[CH], vreg[CH];
     // Paged KV: the page ids of a tile are fetched one tile ahead of its rows, so that the
     // block-table lookup is not a second memory latency in front of every K/V load (decode is
@@ -177,7 +201,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         if (!bt) return;
 #pragma unroll
         for (int i = 0; i < CH; i++) {
-            const int grow = n * DEC_BN + (tid + i * NT) / CPR;
+            const int grow = n * DEC_BN + (tid + i * NT) / CPRR;
             const int safe = grow < sk ? grow : 0;
             pg[i] = bt[p.page_shift >= 0 ? safe >> p.page_shift : safe / p.page_size];
         }
@@ -186,7 +210,8 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int c = tid + i * NT;
-            const int row = c / CPR, ch = c % CPR;
+            const int row = c / CPRR, chr = c % CPRR;
+            const int hd = chr / CPR, ch = chr % CPR;
             const int grow = n * DEC_BN + row;
             const bool ok = grow < sk && ch * 8 < p.d;
             int64_t ko, vo;
@@ -199,6 +224,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
                 ko = (int64_t)grow * p.k_rs;
                 vo = (int64_t)grow * p.v_rs;
             }
+            if constexpr (HPB > 1) { ko += (int64_t)hd * p.k_hs; vo += (int64_t)hd * p.v_hs; }
             kreg[i] = ok ? *(const i32x4 *)(kg + ko + ch * 8) : i32x4{0, 0, 0, 0};
             vreg[i] = ok ? *(const i32x4 *)(vg + vo + ch * 8) : i32x4{0, 0, 0, 0};
         }
@@ -207,14 +233,13 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int c = tid + i * NT;
-            const int row = c / CPR, ch = c % CPR;
-            const int off = lds_off<DP>(row, ch);
+            const int off = lds_off<ROWE>(c / CPRR, c % CPRR);
             *(i32x4 *)(smem + off) = kreg[i];
             *(i32x4 *)(smem + Cfg::TILE_BYTES + off) = vreg[i];
         }
     };
 
-    // Q fragments: every wave holds the same 32 query rows
+    // Q fragments: every wave (of a head) holds the same 32 query rows
     i32x4 qf[KS];
     {
         const int row = q0 + r;
@@ -241,7 +266,6 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             }
         }
     }
-
     char *q_lds = smem + Cfg::KV_LDS;  // fragment s of lane l at (s * 64 + l) * 16
     if constexpr (Cfg::Q_LDS > 0) {
         if (wave_id == 0) {
@@ -266,7 +290,8 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 
     const char *kb = smem;
     const char *vb = smem + Cfg::TILE_BYTES;
-    const int wrow = 32 * wave;  // this wave's rows of the staged tile
+    const int wrow = 32 * wave;      // this wave's rows of the staged tile
+    const int hch = hsel * CPR;      // first 16-byte chunk of this wave's head in a staged row
 
     load_pages(n_max - 1);
     load_tile(n_max - 1);
@@ -284,7 +309,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         for (int j = 0; j < 16; j++) s[j] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const i32x4 kf = *(const i32x4 *)(kb + lds_off<DP>(wrow + r, 2 * ks + hh));
+            const i32x4 kf = *(const i32x4 *)(kb + lds_off<ROWE>(wrow + r, hch + 2 * ks + hh));
             if constexpr (Cfg::Q_LDS > 0) s = mma32<BF16>(kf, *(const i32x4 *)(q_lds + (ks * 64 + lane) * 16), s);
             else s = mma32<BF16>(kf, qf[ks], s);
         }
@@ -344,9 +369,9 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const int row0 = wrow + 16 * ks + 4 * hh + tr_q;
-                const int ch = 4 * (db + dhalf * NDB) + 2 * tr_g + (tr_p >> 1);
-                const s16x4 v0 = lds_read_tr16(vb + lds_off<DP>(row0, ch) + 8 * (tr_p & 1));
-                const s16x4 v1 = lds_read_tr16(vb + lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1));
+                const int ch = hch + 4 * (db + dhalf * NDB) + 2 * tr_g + (tr_p >> 1);
+                const s16x4 v0 = lds_read_tr16(vb + lds_off<ROWE>(row0, ch) + 8 * (tr_p & 1));
+                const s16x4 v1 = lds_read_tr16(vb + lds_off<ROWE>(row0 + 8, ch) + 8 * (tr_p & 1));
                 i32x4 vf;
                 const i32x2 a0 = __builtin_bit_cast(i32x2, v0), a1 = __builtin_bit_cast(i32x2, v1);
                 vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a1[0]; vf[3] = a1[1];
@@ -356,8 +381,9 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         __syncthreads();  // everyone is done with the staged tile before it is overwritten
     }
 
-    // ---- merge the four waves' partial states (same algebra as the split combine) ----
-    float *ml = (float *)(smem + DEC_NW * DEC_BM * Cfg::O_ROWB);  // [wave][row][2]
+    // ---- merge the four waves' partial states of a head (same algebra as the split combine) ----
+    char *area = smem + hsel * Cfg::O_HEAD;
+    float *ml = (float *)(area + DEC_NW * DEC_BM * Cfg::O_ROWB);  // [wave][row][2]
     const float l_w = half_swap_sum(l_run);
     if (hh == 0 && dhalf == 0) {
         ml[(wave * DEC_BM + r) * 2 + 0] = m_run;
@@ -377,7 +403,7 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     const bool bad = (l_all == 0.f) || (l_all != l_all);
     const float inv = bad ? 1.f : 1.f / l_all;
     const float f = my_scale * inv;
-    char *ob = smem + wave * DEC_BM * Cfg::O_ROWB;
+    char *ob = area + wave * DEC_BM * Cfg::O_ROWB;
 #pragma unroll
     for (int db = 0; db < NDB; db++)
 #pragma unroll
@@ -387,18 +413,18 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             for (int t = 0; t < 4; t++) w4[t] = o[db][4 * g4 + t] * f;
             *(f32x4 *)(ob + r * Cfg::O_ROWB + (32 * (db + dhalf * NDB) + 8 * g4 + 4 * hh) * 4) = w4;
         }
-    if (wave_id == 0 && hh == 0 && q0 + r < sq) {
+    if (wave == 0 && dhalf == 0 && hh == 0 && q0 + r < sq) {
         // softmax.h:179: LSE = max*scale + log(sum); empty -> +inf (final) / -inf (split partial)
         lse_g[q0 + r] = bad ? (is_split ? -INFINITY : INFINITY) : m_all * p.scale + __logf(l_all);
     }
     __syncthreads();
     // each thread sums 8 consecutive d of one row over the waves
-    for (int c = tid; c < DEC_BM * CPR; c += NT) {
+    for (int c = tid_h; c < DEC_BM * CPR; c += NT_H) {
         const int row = c / CPR, ch = c % CPR;
         f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < DEC_NW; w++) {
-            const char *src = smem + (w * DEC_BM + row) * Cfg::O_ROWB + ch * 32;
+            const char *src = area + (w * DEC_BM + row) * Cfg::O_ROWB + ch * 32;
             a0 += *(const f32x4 *)src;
             a1 += *(const f32x4 *)(src + 16);
         }
@@ -583,18 +609,33 @@ static hipError_t launch_combine(const KParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int DP, bool BF16>
-static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
-    using Cfg = DecodeCfg<DP>;
+// Heads per workgroup (512 contiguous bytes per key) when the query and KV heads pair up one to one.
+template <int DP>
+static int decode_heads_per_block(const KParams &p) {
+    constexpr int want = DP == 128 ? 2 : 1;
+    if (want == 1 || g_tuning[1] == 1) return 1;
+    return (p.h == p.h_k && p.h % want == 0) ? want : 1;
+}
+
+template <int DP, bool BF16, int HPB>
+static hipError_t launch_decode_hpb(const KParams &p, hipStream_t stream) {
+    using Cfg = DecodeCfg<DP, HPB>;
     const int n_mblocks = (p.seqlen_q + DEC_BM - 1) / DEC_BM;
-    const long long blocks = (long long)n_mblocks * p.b * p.h * p.num_splits;
+    const long long blocks = (long long)n_mblocks * p.b * (p.h / HPB) * p.num_splits;
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_decode_kernel<DP, BF16>;
+    auto kern = fwd_decode_kernel<DP, BF16, HPB>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
+    return hipGetLastError();
+}
+
+template <int DP, bool BF16>
+static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
     hipError_t e;
-    e = hipGetLastError();
+    constexpr int HPB = DP == 128 ? 2 : 1;
+    if (decode_heads_per_block<DP>(p) == 1) e = launch_decode_hpb<DP, BF16, 1>(p, stream);
+    else e = launch_decode_hpb<DP, BF16, HPB>(p, stream);
     if (e != hipSuccess) return e;
     if (p.num_splits > 1) e = launch_combine(p, stream);
     return e;

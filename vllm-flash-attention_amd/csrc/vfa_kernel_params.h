@@ -12,6 +12,7 @@ namespace vfa {
 // Development switches (kernel-variant selection for A/B timing inside one process), set through
 // vfa_debug_set_tuning(); all zero = the shipped choices.
 //   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one
+//   [1] decode kernel: 0 = auto, 1 = always one head per workgroup
 //   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs
 extern int g_tuning[8];
 
