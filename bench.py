@@ -188,11 +188,12 @@ def pmc_traffic(workload, kernels):
     """HBM bytes per launch of the named kernel(s), from the committed PMC passes (FETCH_SIZE and
     WRITE_SIZE are collected with rocprofv3 in runs of their own, never inside a timed run); None
     when no pass exists for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     try:
-        table = json.load(open(path)).get(workload.replace("_fwd", ""), {})
+        table = json.load(open(found[-1])).get(workload.replace("_fwd", ""), {})
         return sum(table[k]["hbm_bytes"] for k in kernels.split("+")) if table else None
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None
 
 

@@ -4,7 +4,7 @@
 # the chain stops at the first failure.
 set -e -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
-O=gpurun_out/final
+O=gpurun_out/final   # copy what is to be kept into profiles/rNN_*
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/pytest.log 2>&1
