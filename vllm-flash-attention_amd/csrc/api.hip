@@ -125,6 +125,7 @@ static void fill_common(const vfa_params *p, KParams &k, int seqlen_q_for_fold, 
     k.wl = wl; k.wr = wr;
     k.is_local = (wl >= 0 || wr >= 0) && !k.is_causal;
     k.dbg_flags = vfa::g_tuning[2];
+    k.pack_gqa = 0;
     k.num_splits = 1;
     // flash_api.cpp:105-113: keep probability, its 8-bit threshold (rounded down: the test is <=)
     k.p_keep = 1.f - p->p_dropout;
@@ -359,7 +360,10 @@ extern "C" int vfa_mha_fwd_kvcache_noalloc(const vfa_params *p) {
     if (q.num_splits == 0) {
         // the count the allocating path's caller would pick (set_params_splitkv), lowered until the
         // partial results fit the static array
-        q.num_splits = vfa_splitkv_num_splits(p->b, p->h, p->d, p->seqlen_k, p->seqlen_q, num_cus());
+        const int ratio = p->h / p->h_k;
+        q.num_splits = (ratio > 1 && p->seqlen_q * ratio <= 32)
+                           ? vfa_splitkv_num_splits(p->b, p->h_k, p->d, p->seqlen_k, 1, num_cus())
+                           : vfa_splitkv_num_splits(p->b, p->h, p->d, p->seqlen_k, p->seqlen_q, num_cus());
         while (q.num_splits > 1 && split_scratch_floats(p, q.num_splits, nullptr) > cap) q.num_splits--;
     }
     if (q.num_splits > 1) {

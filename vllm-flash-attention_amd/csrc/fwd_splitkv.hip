@@ -118,43 +118,60 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     // head x of every batch entry on XCD x, which measured best (b128 kv8192 hk8: 747 us).  With
     // several splits the ids are regrouped so that each XCD owns one contiguous range of the index,
     // i.e. all heads and splits of a batch entry run on one XCD at about the same time: 727 us
-    // against 801 us ungrouped at 4 splits, 737 against 783 at 2.
+    // against 801 us ungrouped at 4 splits, 737 against 783 at 2.  Likewise with several row blocks
+    // per head, which all read the head's K/V: they share one XCD's L2.
     int L = blockIdx.x;
-    if ((p.num_splits > 1) != ((p.dbg_flags & 1) != 0)) {
+    if ((p.num_splits > 1 || n_mblocks > 1) != ((p.dbg_flags & 1) != 0)) {
         const int per_xcd = gridDim.x / 8;
         if (L < per_xcd * 8) L = (L % 8) * per_xcd + L / 8;
     }
-    const int n_hblocks = p.h / HPB;
+    // With pack_gqa the grid walks the KV heads and the rows of a workgroup are the (query position,
+    // query head of the group) pairs of its KV head, row i = position i / ratio, head i % ratio: the
+    // query heads that share a KV head read its K/V once instead of once each (one, two, ... query
+    // tokens per sequence against a long cache: speculative decoding, small chunks, ALiBi decode).
+    const int ratio = p.pack_gqa ? p.h_ratio : 1;
+    const int n_hblocks = (p.pack_gqa ? p.h_k : p.h) / HPB;
     const int m_block = L % n_mblocks; L /= n_mblocks;
     const int bidh0 = (L % n_hblocks) * HPB; L /= n_hblocks;
     const int split = L % p.num_splits; L /= p.num_splits;
     const int bidb = L;
-    const int bidh = bidh0 + hsel;         // this wave's query head
-    const int hk0 = bidh0 / p.h_ratio;     // first KV head of the workgroup (HPB = 2 only runs with h == h_k)
+    const int vh = bidh0 + hsel;           // this wave's head: a KV head when packed, else a query head
+    const int hk0 = p.pack_gqa ? bidh0 : bidh0 / p.h_ratio;  // first KV head of the workgroup
     const bool is_split = p.num_splits > 1;
 
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
-    if (m_block * DEC_BM >= sq) return;
+    const int sqv = sq * ratio;            // rows of this (batch, head)
+    if (m_block * DEC_BM >= sqv) return;
     const int q0 = m_block * DEC_BM;
+    const int pos_lo = q0 / ratio, pos_hi = (q0 + DEC_BM - 1) / ratio;  // query positions of the block's rows
 
     // key tile range of this split (flash_fwd_kernel.h:504-512), in units of DEC_BN keys; the
     // per-split block count comes from the capacity p.seqlen_k like the reference's.
     const int per = (((p.seqlen_k + DEC_BN - 1) / DEC_BN) + p.num_splits - 1) / p.num_splits;
     int n_min = split * per;
-    if (p.is_local) n_min = max(n_min, (q0 + sk - sq - p.wl) / DEC_BN);
+    if (p.is_local) n_min = max(n_min, (pos_lo + sk - sq - p.wl) / DEC_BN);
     int n_max = min((sk + DEC_BN - 1) / DEC_BN, (split + 1) * per);
     if (p.is_causal || p.is_local)
-        n_max = min(n_max, (q0 + DEC_BM + sk - sq + p.wr + DEC_BN - 1) / DEC_BN);
+        n_max = min(n_max, (pos_hi + 1 + sk - sq + p.wr + DEC_BN - 1) / DEC_BN);
 
-    const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) +
-                               (int64_t)bidh * p.q_hs;
-    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
-                         (int64_t)bidh * p.o_hs;
-    const int64_t acc_row0 = (((int64_t)split * p.b + bidb) * p.h + bidh) * p.seqlen_q;
-    float *lse_g = is_split ? p.lseaccum + acc_row0
-                            : p.lse + ((int64_t)bidb * p.h + bidh) * p.seqlen_q;
-    float *oacc_g = is_split ? p.oaccum + acc_row0 * p.d : nullptr;
+    const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb);
+    unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb);
+    // row i of this wave's head -> query position and query head, and where its results go
+    auto row_pos = [&](int i) { return i / ratio; };
+    auto row_head = [&](int i) { return vh * ratio + (i - (i / ratio) * ratio); };
+    auto lse_ptr = [&](int i) -> float * {
+        const int64_t bh = (int64_t)bidb * p.h + row_head(i);
+        return is_split ? p.lseaccum + ((int64_t)split * p.b * p.h + bh) * p.seqlen_q + row_pos(i)
+                        : p.lse + bh * p.seqlen_q + row_pos(i);
+    };
+    auto oacc_ptr = [&](int i) -> float * {
+        const int64_t bh = (int64_t)bidb * p.h + row_head(i);
+        return p.oaccum + (((int64_t)split * p.b * p.h + bh) * p.seqlen_q + row_pos(i)) * p.d;
+    };
+    auto o_ptr = [&](int i) -> unsigned short * {
+        return og + (int64_t)row_pos(i) * p.o_rs + (int64_t)row_head(i) * p.o_hs;
+    };
     // threads that share this wave's head: the whole workgroup, or its group of 4 waves
     const int tid_h = HPB > 1 ? (tid & (DEC_NT - 1)) : tid;
     constexpr int NT_H = HPB > 1 ? DEC_NT : NT;
@@ -163,18 +180,18 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         // flash_fwd_kernel.h:513-552: O = 0 and LSE = -inf (split) / +inf (final)
         for (int c = tid_h; c < DEC_BM * CPR; c += NT_H) {
             const int row = q0 + c / CPR, ch = c % CPR;
-            if (row < sq && ch * 8 < p.d) {
+            if (row < sqv && ch * 8 < p.d) {
                 if (is_split) {
-                    float *dst = oacc_g + (int64_t)row * p.d + ch * 8;
+                    float *dst = oacc_ptr(row) + ch * 8;
                     *(f32x4 *)dst = f32x4{0, 0, 0, 0};
                     *(f32x4 *)(dst + 4) = f32x4{0, 0, 0, 0};
                 } else {
-                    *(i32x4 *)(og + (int64_t)row * p.o_rs + ch * 8) = i32x4{0, 0, 0, 0};
+                    *(i32x4 *)(o_ptr(row) + ch * 8) = i32x4{0, 0, 0, 0};
                 }
             }
         }
         for (int c = tid_h; c < DEC_BM; c += NT_H)
-            if (q0 + c < sq) lse_g[q0 + c] = is_split ? -INFINITY : INFINITY;
+            if (q0 + c < sqv) *lse_ptr(q0 + c) = is_split ? -INFINITY : INFINITY;
         return;
     }
 
@@ -243,8 +260,9 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     i32x4 qf[KS];
     {
         const int row = q0 + r;
-        const bool rok = row < sq;
-        const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+        const bool rok = row < sqv;
+        const int rsafe = rok ? row : q0;
+        const unsigned short *qr = qg + (int64_t)row_pos(rsafe) * p.q_rs + (int64_t)row_head(rsafe) * p.q_hs;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const int col = 16 * s + 8 * hh;
@@ -252,8 +270,8 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
         }
         if (p.knew && p.rotary_dim > 0 && rok) {
             // flash_fwd_kernel.h:785-824: the query is rotated with position seqlen_k_cache
-            // (+ its row index when causal or local)
-            int pos = bi.sk_cache + ((p.is_causal || p.is_local) ? row : 0);
+            // (+ its own position when causal or local)
+            int pos = bi.sk_cache + ((p.is_causal || p.is_local) ? row_pos(row) : 0);
             if (p.seqlen_ro > 0) pos = min(pos, p.seqlen_ro - 1);  // never past the table's end
             const int half = p.rotary_dim / 2;
             const unsigned short *cosp = (const unsigned short *)p.rotary_cos + (int64_t)pos * half;
@@ -284,7 +302,8 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 
     float alibi = 0.f;
     const bool has_alibi = p.alibi_slopes != nullptr;
-    if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
+    const int my_pos = row_pos(q0 + r);  // query position of this lane's row
+    if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + row_head(min(q0 + r, sqv - 1))] / p.scale;
     const float c2 = p.scale_log2;
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
 
@@ -316,10 +335,10 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
 
         const int c0 = n * DEC_BN + wrow;
         bool need = has_alibi || (c0 + 32 > sk);
-        if (p.is_causal || p.is_local) need = need || (c0 + 32 > q0 + 1 + sk - sq + p.wr);
-        if (p.is_local) need = need || (c0 < q0 + 31 + sk - sq - p.wl);
+        if (p.is_causal || p.is_local) need = need || (c0 + 32 > pos_lo + 1 + sk - sq + p.wr);
+        if (p.is_local) need = need || (c0 < pos_hi + sk - sq - p.wl);
         if (need) {
-            const int row = q0 + r;
+            const int row = my_pos;
             const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
             const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
 #pragma unroll
@@ -413,9 +432,9 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             for (int t = 0; t < 4; t++) w4[t] = o[db][4 * g4 + t] * f;
             *(f32x4 *)(ob + r * Cfg::O_ROWB + (32 * (db + dhalf * NDB) + 8 * g4 + 4 * hh) * 4) = w4;
         }
-    if (wave == 0 && dhalf == 0 && hh == 0 && q0 + r < sq) {
+    if (wave == 0 && dhalf == 0 && hh == 0 && q0 + r < sqv) {
         // softmax.h:179: LSE = max*scale + log(sum); empty -> +inf (final) / -inf (split partial)
-        lse_g[q0 + r] = bad ? (is_split ? -INFINITY : INFINITY) : m_all * p.scale + __logf(l_all);
+        *lse_ptr(q0 + r) = bad ? (is_split ? -INFINITY : INFINITY) : m_all * p.scale + __logf(l_all);
     }
     __syncthreads();
     // each thread sums 8 consecutive d of one row over the waves
@@ -428,16 +447,16 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             a0 += *(const f32x4 *)src;
             a1 += *(const f32x4 *)(src + 16);
         }
-        if (q0 + row < sq && ch * 8 < p.d) {
+        if (q0 + row < sqv && ch * 8 < p.d) {
             if (is_split) {
-                float *dst = oacc_g + (int64_t)(q0 + row) * p.d + ch * 8;
+                float *dst = oacc_ptr(q0 + row) + ch * 8;
                 *(f32x4 *)dst = a0;
                 *(f32x4 *)(dst + 4) = a1;
             } else {
                 i32x4 w;
                 w[0] = pack2<BF16>(a0[0], a0[1]); w[1] = pack2<BF16>(a0[2], a0[3]);
                 w[2] = pack2<BF16>(a1[0], a1[1]); w[3] = pack2<BF16>(a1[2], a1[3]);
-                *(i32x4 *)(og + (int64_t)(q0 + row) * p.o_rs + ch * 8) = w;
+                *(i32x4 *)(o_ptr(q0 + row) + ch * 8) = w;
             }
         }
     }
@@ -614,14 +633,15 @@ template <int DP>
 static int decode_heads_per_block(const KParams &p) {
     constexpr int want = DP == 128 ? 2 : 1;
     if (want == 1 || g_tuning[1] == 1) return 1;
-    return (p.h == p.h_k && p.h % want == 0) ? want : 1;
+    return ((p.h == p.h_k || p.pack_gqa) && p.h_k % want == 0) ? want : 1;
 }
 
 template <int DP, bool BF16, int HPB>
 static hipError_t launch_decode_hpb(const KParams &p, hipStream_t stream) {
     using Cfg = DecodeCfg<DP, HPB>;
-    const int n_mblocks = (p.seqlen_q + DEC_BM - 1) / DEC_BM;
-    const long long blocks = (long long)n_mblocks * p.b * (p.h / HPB) * p.num_splits;
+    const int rows = p.seqlen_q * (p.pack_gqa ? p.h_ratio : 1);
+    const int n_mblocks = (rows + DEC_BM - 1) / DEC_BM;
+    const long long blocks = (long long)n_mblocks * p.b * ((p.pack_gqa ? p.h_k : p.h) / HPB) * p.num_splits;
     if (blocks <= 0) return hipSuccess;
     auto kern = fwd_decode_kernel<DP, BF16, HPB>;
     static std::atomic<uint64_t> lds_set{0};
@@ -645,7 +665,10 @@ static hipError_t launch_decode(const KParams &p, hipStream_t stream) {
 // split variants).
 hipError_t run_fwd_combine(const KParams &p, hipStream_t stream) { return launch_combine(p, stream); }
 
-hipError_t run_fwd_splitkv(const KParams &p, hipStream_t stream) {
+hipError_t run_fwd_splitkv(const KParams &p_in, hipStream_t stream) {
+    KParams p = p_in;
+    // query heads that share a KV head go into the rows of one workgroup (see the kernel)
+    p.pack_gqa = p.h_ratio > 1 && !(g_tuning[2] & 2);
     const bool bf = p.is_bf16;
     if (p.d <= 64) return bf ? launch_decode<64, true>(p, stream) : launch_decode<64, false>(p, stream);
     if (p.d <= 128) return bf ? launch_decode<128, true>(p, stream) : launch_decode<128, false>(p, stream);

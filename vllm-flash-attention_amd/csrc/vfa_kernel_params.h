@@ -13,7 +13,8 @@ namespace vfa {
 // vfa_debug_set_tuning(); all zero = the shipped choices.
 //   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one
 //   [1] decode kernel: 0 = auto, 1 = always one head per workgroup
-//   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs
+//   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs, bit 1 turns off
+//       the packing of grouped query heads into the rows of their KV head
 extern int g_tuning[8];
 
 // Compute units of the current device (cached per thread and device).
@@ -53,6 +54,7 @@ struct KParams {
     int64_t o_bs, o_rs, o_hs;
     int b, h, h_k, h_ratio, d;
     int dbg_flags;
+    int pack_gqa;               // decode kernel only: rows = (query position, query head of the KV group)
     int seqlen_q, seqlen_k;     // max query length, max key length / cache capacity
     const int *cu_seqlens_q;    // b+1 or null
     const int *cu_seqlens_k;    // b+1 cumulative, or b lengths when !k_cumulative, or null
