@@ -17,6 +17,16 @@ def main():
     libs = [a for a in sys.argv[1:] if a.endswith(".so")]
     hip = bench.Hip()
     handles = [cabi.load(os.path.abspath(p)) for p in libs]
+    # --tune-last=K:V applies a development switch to the last library only (load a COPY of the
+    # library file to compare two settings of one build)
+    for a in sys.argv[1:]:
+        if a.startswith("--tune="):
+            k, v = a.split("=", 1)[1].split(":")
+            for h in handles:
+                h.vfa_debug_set_tuning(int(k), int(v))
+        if a.startswith("--tune-last="):
+            k, v = a.split("=", 1)[1].split(":")
+            handles[-1].vfa_debug_set_tuning(int(k), int(v))
     stream = torch.cuda.current_stream().cuda_stream
     for b, s, h, hk, d, causal in SHAPES:
         for data in ("random", "zeros"):

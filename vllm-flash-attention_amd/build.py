@@ -23,10 +23,11 @@ OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
-               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip"]
+               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip", "fwd_prefill_w64.hip"]
 # Kernels built for one wave per SIMD (up to 512 registers): MFMA results that vector instructions
 # consume must be allocated in the arch VGPRs, not forced into the accumulator half of the file.
-EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "fwd_prefill_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # the dropout translation units are one-line includes of the kernel sources
 EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"],
               "fwd_prefill_split.hip": ["fwd_prefill.hip"]}

@@ -84,46 +84,6 @@ struct PrefillCfg {
     static_assert(TILE_CHUNKS % NT == 0, "tile must divide over threads");
 };
 
-// block -> (batch, head, m_block).  Blocks b and b+8 share an XCD (round-robin dispatch), so give
-// each XCD whole (batch, kv-head) pairs: their K/V then stay in that XCD's L2 while the pair's
-// query heads and m-blocks stream through.  Within an XCD the pairs are taken in groups of G, and
-// within a group the m-blocks go heaviest first ACROSS its pairs (the last m-block of every pair,
-// then the one before, ...): under a causal mask m-block m costs (m + 1) tiles, and pair-by-pair
-// order starts the heavy blocks of the next pair only as the light ones of this pair finish, which
-// shows as a tail of up to one heavy block per CU.  G covers about two rounds of the XCD's
-// `slots` resident workgroups, so the co-resident blocks still come from few pairs.
-__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, const int slots, int &bidb,
-                                          int &bidh, int &m_block) {
-    const int g = p.h_ratio;
-    const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
-    const int P = p.b * p.h_k;
-    const int L = blockIdx.x;
-    const int full = (P / 8) * 8 * W;
-    int pair, head, mi;
-    if (L < full) {
-        const int x = L & 7, s = L >> 3;
-        const int ppx = P / 8;
-        const int G = max(1, min(ppx, (2 * slots + W - 1) / W));
-        const int grp = s / (G * W);
-        const int within = s - grp * G * W;
-        const int Gl = min(G, ppx - grp * G);
-        mi = within / (Gl * g);
-        const int rest = within - mi * (Gl * g);
-        pair = (grp * G + rest / g) * 8 + x;
-        head = rest % g;
-    } else {
-        // the last P % 8 pairs, spread over all XCDs: heaviest m-blocks first across them
-        const int Lr = L - full, R = P - (P / 8) * 8;
-        mi = Lr / (R * g);
-        const int rest = Lr - mi * (R * g);
-        pair = (P / 8) * 8 + rest / g;
-        head = rest % g;
-    }
-    bidb = pair / p.h_k;
-    bidh = (pair % p.h_k) * g + head;
-    m_block = n_mblocks - 1 - mi;
-}
-
 // LD = 1: K/V are contiguous per (batch, head) (no block table) and fit a 32-bit byte offset, so
 // tiles are fetched with buffer loads whose descriptor ends at the last valid key row: the key
 // tail and the head-dim padding read as zeros without any predication or 64-bit address
@@ -774,8 +734,12 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 }
 
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
+bool fwd_prefill_w64_ok(const KParams &p);
+hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
+
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
+    if (g_tuning[4] == 1 && fwd_prefill_w64_ok(p)) return run_fwd_prefill_w64(p, stream);
     // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) against two
     // independent 4-wave blocks per CU, which overlap each other's prologue / epilogue / barrier
     // stalls and split a causal diagonal more finely.  Measured on MI355X (bf16, 16k..64k tokens,

@@ -15,6 +15,7 @@ namespace vfa {
 //   [1] decode kernel: 0 = auto, 1 = always one head per workgroup
 //   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs, bit 1 turns off
 //       the packing of grouped query heads into the rows of their KV head
+//   [4] forward at 64 < d <= 128: 1 = the 64-rows-per-wave kernel wherever it applies
 extern int g_tuning[8];
 
 // Compute units of the current device (cached per thread and device).
@@ -270,5 +271,46 @@ __device__ __forceinline__ unsigned keep_bits_klane(unsigned long long seed, uns
     __builtin_amdgcn_s_waitcnt(0xC07F);
     return keep;
 }
+
+// block -> (batch, head, m_block).  Blocks b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD whole (batch, kv-head) pairs: their K/V then stay in that XCD's L2 while the pair's
+// query heads and m-blocks stream through.  Within an XCD the pairs are taken in groups of G, and
+// within a group the m-blocks go heaviest first ACROSS its pairs (the last m-block of every pair,
+// then the one before, ...): under a causal mask m-block m costs (m + 1) tiles, and pair-by-pair
+// order starts the heavy blocks of the next pair only as the light ones of this pair finish, which
+// shows as a tail of up to one heavy block per CU.  G covers about two rounds of the XCD's
+// `slots` resident workgroups, so the co-resident blocks still come from few pairs.
+__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, const int slots, int &bidb,
+                                          int &bidh, int &m_block) {
+    const int g = p.h_ratio;
+    const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
+    const int P = p.b * p.h_k;
+    const int L = blockIdx.x;
+    const int full = (P / 8) * 8 * W;
+    int pair, head, mi;
+    if (L < full) {
+        const int x = L & 7, s = L >> 3;
+        const int ppx = P / 8;
+        const int G = max(1, min(ppx, (2 * slots + W - 1) / W));
+        const int grp = s / (G * W);
+        const int within = s - grp * G * W;
+        const int Gl = min(G, ppx - grp * G);
+        mi = within / (Gl * g);
+        const int rest = within - mi * (Gl * g);
+        pair = (grp * G + rest / g) * 8 + x;
+        head = rest % g;
+    } else {
+        // the last P % 8 pairs, spread over all XCDs: heaviest m-blocks first across them
+        const int Lr = L - full, R = P - (P / 8) * 8;
+        mi = Lr / (R * g);
+        const int rest = Lr - mi * (R * g);
+        pair = (P / 8) * 8 + rest / g;
+        head = rest % g;
+    }
+    bidb = pair / p.h_k;
+    bidh = (pair % p.h_k) * g + head;
+    m_block = n_mblocks - 1 - mi;
+}
+
 
 }  // namespace vfa
