@@ -1,0 +1,42 @@
+"""The 64-rows-per-wave forward kernel keeps O and Q in accumulator registers a[0:191] that only its
+asm statements touch.  The compiler knows them only as clobbers, so this test compiles the kernel
+to assembly and checks that no instruction the COMPILER emitted (outside the asm blocks) reads or
+writes one of them: a value parked there between two statements would silently corrupt O or Q."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vllm-flash-attention_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_compiler_never_touches_the_owned_accumulator_registers():
+    tmp = tempfile.mkdtemp()
+    try:
+        out = os.path.join(tmp, "w64.s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                               "-I", CSRC, "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only", "-w",
+                               os.path.join(CSRC, "fwd_prefill_w64.hip"), "-o", out])
+        in_asm, bad, kernels = False, [], 0
+        for line in open(out):
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm:
+                if "fwd_prefill_w64_kernel" in line and line.rstrip().endswith(":"):
+                    kernels += 1
+                for m in re.finditer(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]", line):
+                    lo = int(m.group(1) or m.group(2))
+                    if lo < 192 and not line.lstrip().startswith((";", ".")):
+                        bad.append(line.strip())
+        assert kernels >= 2, "kernel symbols not found in the assembly"
+        assert not bad, "compiler-emitted instructions touch owned AGPRs:\n" + "\n".join(bad[:10])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

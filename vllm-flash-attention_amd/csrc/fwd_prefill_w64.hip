@@ -38,7 +38,7 @@ constexpr int DP = 128, BN = 64, NW = 4, QM = 64, BM = NW * QM;
 constexpr int CPR = DP / 8, ROWB = DP * 2, TILE = BN * ROWB;
 constexpr int KS = DP / 16, NDB = DP / 32;
 constexpr int O_ROWB = DP * 2 + 16;
-constexpr int KV_LDS = 4 * TILE;                 // K0 K1 V0 V1
+constexpr int KV_LDS = 5 * TILE;                 // K0 K1 K2 V0 V1
 constexpr int O_LDS = NW * QM * O_ROWB;
 constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
 }  // namespace f64
@@ -141,7 +141,7 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
     };
     auto dma_v = [&](const int n, const int slot, const int i) __attribute__((always_inline)) {
         const unsigned rows = (unsigned)(n * BN + RPI * NW * i);
-        dma_16b_to_lds(v_rsrc, dv_voff + rows * v_rs2, lds0 + (2 + slot) * TILE + (wave + NW * i) * 1024);
+        dma_16b_to_lds(v_rsrc, dv_voff + rows * v_rs2, lds0 + (3 + slot) * TILE + (wave + NW * i) * 1024);
     };
 
     // ---- Q fragments (B operand of S^T = K Q^T) into a[128:191]: fragment 8 qh + s, lane (r, hh)
@@ -186,6 +186,7 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
     f32x16 sA[2][2], sB[2][2];  // S^T tiles [query half][key half], two pipeline stages
     i32x4 pf[2][4];             // P^T fragments [query half][k-step of 16 keys] of the tile in flight
     float mc[2] = {0.f, 0.f};   // reference points times scale_log2 (of the tile whose P is being built)
+    float nmc[2] = {0.f, 0.f};  // their negatives (the addend of the exponent's multiply-add)
     float alpha_pend[2] = {1.f, 1.f};
     bool rescale_pend = false;
 
@@ -224,7 +225,7 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
     };
     // row maxima of a tile and the (lazy) move of the reference point: softmax.h:135-166
 #ifndef W64_RESCALE
-#define W64_RESCALE 4.f
+#define W64_RESCALE 8.f
 #endif
     constexpr float RESCALE_LOG2 = W64_RESCALE;
     auto row_max = [&](f32x16 (&s)[2][2]) __attribute__((always_inline)) {
@@ -250,7 +251,10 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
             rescale_pend = true;
         }
 #pragma unroll
-        for (int qh = 0; qh < 2; qh++) mc[qh] = ((m_run[qh] == -INFINITY) ? 0.f : m_run[qh]) * c2;
+        for (int qh = 0; qh < 2; qh++) {
+            mc[qh] = ((m_run[qh] == -INFINITY) ? 0.f : m_run[qh]) * c2;
+            nmc[qh] = -mc[qh];
+        }
     };
     // exponentials of 16 keys (k-step e2 of key half kh) of a tile -> one P fragment, row sums
     auto exp_step = [&](f32x16 (&s)[2][2], const int kh, const int qh, const int e2) __attribute__((always_inline)) {
@@ -258,8 +262,11 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const int j = 8 * e2 + 2 * w;
-            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qh][kh][j], c2, -mc[qh]));
-            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qh][kh][j + 1], c2, -mc[qh]));
+            float x0, x1;  // (volatile first reads of the scores: see exp_pair)
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(s[qh][kh][j]), "s"(c2), "v"(nmc[qh]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(s[qh][kh][j + 1]), "s"(c2), "v"(nmc[qh]));
+            const float e0 = __builtin_amdgcn_exp2f(x0);
+            const float e1 = __builtin_amdgcn_exp2f(x1);
             ps += e0 + e1;
             pf[qh][2 * kh + e2][w] = pack2<BF16>(e0, e1);
         }
@@ -284,13 +291,14 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
         asm volatile("s_nop 3" ::: "memory");
         rescale_pend = false;
     };
+    // K tiles go through a ring of three LDS slots (tile of iteration it in slot it % 3, fetched two
+    // iterations ahead), V tiles through two (fetched in the iteration of their S, used by the P V of
+    // the next one).
     auto issue_loads = [&](const int it) __attribute__((always_inline)) {
-        // top of iteration it (tile n = n_max - 1 - it): K(n - 1) for the next iteration's S, V(n)
-        // for the next iteration's P V
         const int n = n_max - 1 - it;
-        if (n - 1 >= n_min) {
+        if (n - 2 >= n_min) {
 #pragma unroll
-            for (int i = 0; i < NI; i++) dma_k(n - 1, (it + 1) & 1, i);
+            for (int i = 0; i < NI; i++) dma_k(n - 2, (it + 2) % 3, i);
         }
 #pragma unroll
         for (int i = 0; i < NI; i++) dma_v(n, it & 1, i);
@@ -323,9 +331,13 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
         }
     };
 
-    // ---- prologue: K of the first tile ----
+    // ---- prologue: K of the first two tiles ----
 #pragma unroll
     for (int i = 0; i < NI; i++) dma_k(n_max - 1, 0, i);
+    if (n_it > 1) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) dma_k(n_max - 2, 1, i);
+    }
     end_iteration();
 
     // iterations before this wave's first tile: it only helps with the loads
@@ -338,11 +350,11 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
         // ---- the wave's first tile: S and the start of its softmax, nothing to overlap with ----
         issue_loads(it);
         if (it & 1) {
-            s_tile(sB, smem + TILE);
+            s_tile(sB, smem + (it % 3) * TILE);
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // S has landed
             start_softmax(sB, n_max - 1 - it);
         } else {
-            s_tile(sA, smem);
+            s_tile(sA, smem + (it % 3) * TILE);
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
             start_softmax(sA, n_max - 1 - it);
         }
@@ -354,13 +366,14 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
         auto exp_pair = [&](f32x16 (&s_)[2][2], auto KH, auto QH, auto E2, auto W) __attribute__((always_inline)) {
             constexpr int kh = decltype(KH)::value, qh = decltype(QH)::value, e2 = decltype(E2)::value, w = decltype(W)::value;
             constexpr int j = 8 * e2 + 2 * w;
-            // The scores come out of asm MFMAs: the empty volatile statement keeps these reads where
-            // they are written among the MFMA statements (the compiler would otherwise move them up
-            // to right behind the MFMA that produced them, before its result has landed).
-            float x0 = s_[qh][kh][j], x1 = s_[qh][kh][j + 1];
-            asm volatile("" : "+v"(x0), "+v"(x1));
-            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x0, c2, -mc[qh]));
-            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x1, c2, -mc[qh]));
+            // The scores come out of asm MFMAs: their first read is a volatile statement, which keeps
+            // its place among the MFMA statements (the compiler would otherwise move the read up to
+            // right behind the MFMA that produced the score, before the result has landed).
+            float x0, x1;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(s_[qh][kh][j]), "s"(c2), "v"(nmc[qh]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(s_[qh][kh][j + 1]), "s"(c2), "v"(nmc[qh]));
+            const float e0 = __builtin_amdgcn_exp2f(x0);
+            const float e1 = __builtin_amdgcn_exp2f(x1);
             l_run[qh] += e0 + e1;
             pf[qh][2 * kh + e2][w] = pack2<BF16>(e0, e1);
         };
@@ -383,9 +396,11 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
             f32x16 (&sNew)[2][2] = PAR ? sB : sA;
             f32x16 (&sOld)[2][2] = PAR ? sA : sB;
             const int n = n_max - 1 - it_;
-            const char *kb = smem + PAR * TILE;
-            const char *vb = smem + (2 + (PAR ^ 1)) * TILE;
-            const bool k_next = n - 1 >= n_min;
+            const int kslot = it_ % 3;
+            const char *kb = smem + kslot * TILE;
+            const char *vb = smem + (3 + (PAR ^ 1)) * TILE;
+            const bool k_next = n - 2 >= n_min;
+            const int kslot_next = kslot == 0 ? 2 : kslot - 1;  // (it_ + 2) % 3
             // ---- phase 1: S(n) | second half of softmax(n + 1) | the loads of this iteration ----
             constexpr int RING = W64_RING;  // fragments read ahead of their MFMAs (+1)
             i32x4 kfr[RING];
@@ -397,15 +412,15 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
                     kfr[nx % RING] = *(const i32x4 *)(kb + k_rd[nx & 7] + 32 * (nx >> 3) * ROWB);
                 mma_s<ks, BF16, ks == 0>(sNew[0][kh], kfr[st % RING]);
                 mma_s<8 + ks, BF16, ks == 0>(sNew[1][kh], kfr[st % RING]);
-                if constexpr (st + 1 < 16) ready(kfr[(st + 1) % RING]);
                 // P dword st of the old tile's key half 1: query half st >> 3, k-step (st >> 2) & 1, dword st & 3
                 exp_pair(sOld, std::integral_constant<int, 1>{}, std::integral_constant<int, (st >> 3)>{},
                          std::integral_constant<int, ((st >> 2) & 1)>{}, std::integral_constant<int, (st & 3)>{});
                 if constexpr ((st & 1) == 1) {
                     constexpr int i = st >> 1;
-                    if constexpr (i < NI) dma_k(n - 1, PAR ^ 1, i, k_next);
+                    if constexpr (i < NI) dma_k(n - 2, kslot_next, i, k_next);
                     else dma_v(n, PAR, i - NI);
                 }
+                if constexpr (st + 1 < 16) ready(kfr[(st + 1) % RING]);  // (after this step's vector work)
             });
             // ---- phase 2: P V of tile n + 1 | row max and first half of softmax(n) ----
             operand_fence(pf[0][0], pf[1][0], pf[0][1], pf[1][1]);
@@ -460,6 +475,7 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
                             alpha_pend[qh] = al;
                             m_run[qh] = m_new;
                             mc[qh] = m_cur * c2;
+                            nmc[qh] = -mc[qh];
                         }
                         rescale_pend = true;
                     }
@@ -489,7 +505,7 @@ fwd_prefill_w64_kernel(const KParams p, const int n_mblocks) {
             ++it;
         }
         // ---- drain: second half of the last tile's softmax and its P V ----
-        const char *vb = smem + (2 + ((n_it - 1) & 1)) * TILE;
+        const char *vb = smem + (3 + ((n_it - 1) & 1)) * TILE;
         if ((n_it - 1) & 1) {
 #pragma unroll
             for (int qh = 0; qh < 2; qh++) { exp_step(sB, 1, qh, 0); exp_step(sB, 1, qh, 1); }
