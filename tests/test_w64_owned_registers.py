@@ -30,7 +30,7 @@ def test_compiler_never_touches_the_owned_accumulator_registers():
             elif "#ASMEND" in line:
                 in_asm = False
             elif not in_asm:
-                if "fwd_prefill_w64_kernel" in line and line.rstrip().endswith(":"):
+                if re.match(r"^_ZN3vfa22fwd_prefill_w64_kernel\S*:", line):
                     kernels += 1
                 for m in re.finditer(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]", line):
                     lo = int(m.group(1) or m.group(2))
