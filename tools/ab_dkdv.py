@@ -20,16 +20,26 @@ def main():
               (4, 4096, 32, 8, 128, True, "bf16"), (2, 8192, 16, 16, 128, True, "bf16"),
               (16, 1024, 16, 16, 128, True, "bf16"), (32, 512, 16, 16, 128, True, "bf16"),
               (4, 2048, 16, 16, 64, True, "bf16"), (8, 4096, 32, 32, 64, True, "bf16")]
-    if len(sys.argv) > 1:
-        shapes = [shapes[int(a)] for a in sys.argv[1:]]
+    variants = [1, 2]   # development switch 0: 1 = 8 waves x 32 keys, 2 = 4 waves x 64 keys, 3 = two-phase 8 waves
+    args = sys.argv[1:]
+    zeros = "--zeros" in args   # all-zero inputs: same instruction stream, no data-dependent power
+    if zeros:
+        args.remove("--zeros")
+    for a in list(args):
+        if a.startswith("--variants="):
+            variants = [int(x) for x in a.split("=")[1].split(",")]
+            args.remove(a)
+    if args:
+        shapes = [shapes[int(a)] for a in args]
     stream = torch.cuda.current_stream().cuda_stream
-    variants = [1, 2]
     for (b, s, h, hk, d, causal, dt) in shapes:
         tdt = torch.bfloat16 if dt == "bf16" else torch.float16
         q = torch.randn(b, s, h, d, device="cuda", dtype=tdt)
         k = torch.randn(b, s, hk, d, device="cuda", dtype=tdt)
         v = torch.randn(b, s, hk, d, device="cuda", dtype=tdt)
         do = torch.randn_like(q)
+        if zeros:
+            q.zero_(); k.zero_(); v.zero_(); do.zero_()
         out = torch.empty_like(q)
         lse = torch.empty(b, h, s, device="cuda", dtype=torch.float32)
         dq = torch.empty_like(q)
@@ -61,8 +71,8 @@ def main():
         for var in variants:
             t = med([x[0] for x in times[var]])
             line += f"  v{var} dkdv {t:.3f} ms ({2 * f / t / 1e9:.0f} TF exec)"
-        dk1, dv1 = res[1][0].float(), res[1][1].float()
-        dk2, dv2 = res[2][0].float(), res[2][1].float()
+        dk1, dv1 = res[variants[0]][0].float(), res[variants[0]][1].float()
+        dk2, dv2 = res[variants[-1]][0].float(), res[variants[-1]][1].float()
         ek = (dk1 - dk2).abs().max().item() / max(1.0, dk1.abs().max().item())
         ev_ = (dv1 - dv2).abs().max().item() / max(1.0, dv1.abs().max().item())
         line += f"  | rel diff dk {ek:.2e} dv {ev_:.2e}  nan {int(torch.isnan(dk2).any() or torch.isnan(dv2).any())}"

@@ -28,6 +28,7 @@
 //                    of 5) and removes the fp32 dQ atomics, which on this chip run at ~1.3 TB/s and
 //                    were the bound of a one-kernel design.
 #include "vfa_kernel_params.h"
+#include "vfa_one_wave_helpers.h"
 
 namespace vfa {
 
@@ -49,6 +50,32 @@ __device__ unsigned long long g_stamps_dkdv[512 * 8 * 8];
 #else
 #define STAMP(slot) do { } while (0)
 #endif
+
+#ifndef VFA_PP_PRIO
+#define VFA_PP_PRIO 2
+#endif
+#ifndef VFA_DKDV_PP_DEFAULT
+#define VFA_DKDV_PP_DEFAULT 0
+#endif
+
+// Scheduling-group directive with a computed (compile-time) size; a compile-time loop.
+template <int MASK, int N>
+__device__ __forceinline__ void sched_group() {
+    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Workgroup barrier that leaves this wave's global -> LDS loads in flight: the LDS reads and
+// writes issued so far are complete (lgkmcnt), vmcnt is not touched.
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Query rows per step of the dK/dV kernel: sub-blocks of 32 rows, QSUB of them per staged slice
 // (one barrier and one load/store round per slice, so a taller slice amortises them).
@@ -116,9 +143,11 @@ struct BwdCfg {
     static constexpr int LDS_BYTES = MAIN_LDS > OUT_LDS ? MAIN_LDS : OUT_LDS;
     static constexpr int KV_CH = KB * CPR / NT;               // chunks per thread per K (or V) tile
     static constexpr int QCH = (QM * CPR + NT - 1) / NT;      // chunks per thread per Q (or dO) slice
+    static constexpr int PP_KLDS = 4;                         // two-phase schedule: K fragments per wave kept in LDS
+    static constexpr int PP_LDS_BYTES = LDS_BYTES + (NW / 2) * PP_KLDS * 1024;   // (waves 0-3 use the gap behind the ring)
 };
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false>
 __global__ void __launch_bounds__(NW * 64, 1)
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
@@ -236,6 +265,368 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const int nh = HS ? max(0, min(p.h_ratio, h_lo + gper) - h_lo) : p.h_ratio;
     const int total_steps = n_steps_per_head * nh;
 
+
+    if constexpr (PP) {
+    // ---- PP: the two waves of a SIMD (waves w and w + 4) alternate between a MATRIX phase and a
+    // VECTOR phase, in anti-phase, with a workgroup barrier after every phase.  Sub-blocks of 32
+    // query rows; for sub-block u a wave runs
+    //   V(u): P = exp2(S), dS = P (dP - delta), both rounded to 16 bit   (vector work only)
+    //   M(u): dV += dO^T P, dK += Q^T dS of sub-block u, then S and dP of sub-block u + 1
+    //         (32 MFMAs, LDS reads, no dependence on this phase's vector results)
+    // and waves 4-7 run one phase behind waves 0-3, so that at any time one wave of a SIMD feeds
+    // the matrix pipe while its partner's exponentials use the vector issue slots the MFMAs leave.
+    // The 32-row Q / dO slices (+ their LSE and delta rows) travel through a ring of four LDS
+    // buffers, requested three sub-blocks ahead by loads that write LDS directly; every wave waits
+    // for its own pieces (counted vmcnt) in front of the barrier that precedes their first read.
+    static_assert(FAST && DP == 128 && NW == 8 && !DROP, "two-phase dK/dV schedule: d = 128, 8 waves");
+    // Ring layout: the four 256-byte row-constant blocks (lse[32], delta[32] as stored in global
+    // memory) first, then the four [Q rows | dO rows] buffers -- every offset the reads add to
+    // their per-lane address then fits the 16-bit immediate field of the DS instructions.
+    constexpr int SL_DO = 32 * DP * 2;        // byte offset of the dO rows in a ring buffer
+    constexpr int SL_BYTES = 2 * SL_DO;
+    constexpr int NRING = 3;
+    constexpr int RING0 = 4 * 256;
+    constexpr int KL0 = RING0 + NRING * SL_BYTES;   // K fragments of waves 0-3; those of waves 4-7 sit behind the V tile
+    static_assert(KL0 + 4 * Cfg::PP_KLDS * 1024 <= Cfg::OFF_VT, "ring and K fragments sit in front of the V tile");
+    static_assert(Cfg::PP_LDS_BYTES <= 160 * 1024, "LDS");
+    const bool grp_b = wave >= 4;
+    int m_lo = 0, m_hi = (sq + 31) / 32;
+    if (p.is_causal || p.is_local) m_lo = max(0, (k0 + sq - sk - p.wr) / 32);
+    if (p.is_local) m_hi = min(m_hi, (k0 + KB + sq - sk + p.wl + 31) / 32);
+    const int T = max(m_hi - m_lo, 0) * nh;
+    const float nis = -1.f / p.scale;
+    auto advance = [&](int &hh_, int &m_) __attribute__((always_inline)) {
+        if (++hh_ == nh) {
+            hh_ = 0;
+            --m_;
+        }
+    };
+    // The last KLDS of a wave's 8 K fragments are kept in LDS (lane order, 1 KiB each, behind the
+    // V tile) and re-read per sub-block like the V fragments: the registers they would take are
+    // what lets the LDS reads run ahead of the MFMAs without spilling.
+    constexpr int KLDS = Cfg::PP_KLDS;
+    const int kl_base = (wave < 4 ? KL0 + wave * KLDS * 1024 : Cfg::LDS_BYTES + (wave - 4) * KLDS * 1024) + lane * 16;
+    __syncthreads();  // every wave has read its K fragments from the K tile, which the stores below overwrite
+#pragma unroll
+    for (int i = 0; i < KLDS; i++) *(i32x4 *)(smem + kl_base + i * 1024) = kf[KS - KLDS + i];
+    __syncthreads();  // every wave has its K fragments: the K tile's space becomes the ring
+    if (T > 0) {
+    // Waves 4-7 do all the loading (at the top of their vector phase, where they have scalar and
+    // memory issue slots to spare): each fetches two 1-KiB pieces (4 rows) of the Q rows and two of
+    // the dO rows of a slice, wave 4 also the 32 LSE and 32 delta values.  Per-lane part of the
+    // offsets: lane -> (row, chunk) of its LDS slot.
+    const int pc0 = wave & 3;                             // this wave's pieces: pc0 and pc0 + 4 (rows + 16)
+    const int row0 = 4 * pc0 + (lane >> 4);
+    const int chs = (lane & 15) ^ swz<DP>(row0);          // (the swizzle of row + 16 is the same)
+    const bool colok = chs * 8 < p.d;
+    const unsigned q_vo = colok ? (unsigned)((row0 * (int)p.q_rs + chs * 8) * 2) : 0x80000000u;
+    const unsigned do_vo = colok ? (unsigned)((row0 * (int)p.do_rs + chs * 8) * 2) : 0x80000000u;
+    int is_h = 0, is_m = m_hi - 1, is_t = 0;  // next sub-block to request
+    // Byte addresses of the batch entry's Q, dO, LSE and delta; a head's descriptor is that base plus
+    // a 32-bit head offset (the dispatch checks that it fits), ending at the head's last valid row, so
+    // that rows past sq read as zeros.
+    const int bidh0 = hk * p.h_ratio + h_lo;
+    const char *q_b = (const char *)((const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb));
+    const char *do_b = (const char *)((const unsigned short *)p.dout + bi.q_off(p.do_bs, p.do_rs, bidb));
+    const char *l_b = (const char *)(p.lse + (int64_t)bidb * p.h * p.seqlen_q);
+    const char *d_b = (const char *)(p.dsoftmax_sum + (int64_t)bidb * p.h * p.seqlen_q_rounded);
+    const unsigned q_bytes = (unsigned)(((int64_t)(sq - 1) * p.q_rs + p.d) * 2);
+    const unsigned do_bytes = (unsigned)(((int64_t)(sq - 1) * p.do_rs + p.d) * 2);
+    const unsigned q_hs2 = (unsigned)p.q_hs * 2, do_hs2 = (unsigned)p.do_hs * 2;
+    i32x4 rq_r, rdo_r, rl_r, rd_r;   // descriptors of the head being requested
+    auto set_head = [&](const int gh) __attribute__((always_inline)) {
+        const unsigned bidh = (unsigned)(bidh0 + gh);
+        rq_r = make_rsrc(q_b + (size_t)(bidh * q_hs2), q_bytes);
+        rdo_r = make_rsrc(do_b + (size_t)(bidh * do_hs2), do_bytes);
+        rl_r = make_rsrc(l_b + (size_t)(bidh * (unsigned)p.seqlen_q * 4), (unsigned)sq * 4);
+        rd_r = make_rsrc(d_b + (size_t)(bidh * (unsigned)p.seqlen_q_rounded * 4), (unsigned)sq * 4);
+    };
+    set_head(0);
+    // Requests past the last sub-block are issued all the same, out of range (they write zeros
+    // into a buffer nobody reads), so that the count of outstanding loads stays the same.
+    auto issue = [&](auto RINGC) __attribute__((always_inline)) {
+        constexpr unsigned RB = RING0 + decltype(RINGC)::value * SL_BYTES, RC = decltype(RINGC)::value * 256;
+        const bool valid = is_t < T;
+        if (nh > 1 && valid) set_head(is_h);
+        const unsigned rows = (unsigned)((valid ? is_m : 0) * 32);
+        if (wave == 4) {
+            const unsigned rv = valid ? (rows + (unsigned)(lane & 31)) * 4 : 0x80000000u;
+            // lane L writes dword L of the 256 bytes
+            if (lane < 32) dma_4b_to_lds(rl_r, rv, RC);
+            else dma_4b_to_lds(rd_r, rv, RC);
+        }
+        const unsigned qv = valid ? q_vo + rows * (unsigned)p.q_rs * 2 : 0x80000000u;
+        const unsigned dv_ = valid ? do_vo + rows * (unsigned)p.do_rs * 2 : 0x80000000u;
+        const unsigned lb = RB + (unsigned)pc0 * 1024u;
+        dma_16b_x4_to_lds(rq_r, qv, valid ? qv + 16 * (unsigned)p.q_rs * 2 : 0x80000000u, lb, lb + 4096u,
+                          rdo_r, dv_, valid ? dv_ + 16 * (unsigned)p.do_rs * 2 : 0x80000000u, lb + SL_DO, lb + SL_DO + 4096u);
+        if (valid) advance(is_h, is_m);
+        ++is_t;
+    };
+    // Once a slice has landed, wave 4 turns its row constants into what the accumulators start
+    // from: -LSE / scale (lanes 0-31) and -delta (lanes 32-63), in place.
+    auto finish_rowc = [&](auto RINGC) __attribute__((always_inline)) {
+        constexpr unsigned RC = decltype(RINGC)::value * 256;
+        if (wave == 4) {
+            float *pr = (float *)(smem + RC) + lane;
+            const float x = *pr;
+            *pr = lane < 32 ? x * nis : -x;
+        }
+    };
+    // wait until at most K of this wave's requests (4 loads each, 6 on wave 4) are in flight
+    auto wait_keep = [&](auto KC) __attribute__((always_inline)) {
+        constexpr int K = decltype(KC)::value;
+        if (wave == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * K) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * K) : "memory");
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    f32x16 s, dp;            // S and dP of the sub-block whose V phase comes next
+    i32x4 pf[2], dsf[2];     // P and dS of the sub-block whose dV / dK products come next
+    bool skip_cur = true, skip_nx = true;
+    int cur_h = 0, cur_m = m_hi - 1, nx_h = 0, nx_m = m_hi - 1;
+    float alibi_cur = 0.f, alibi_nx = 0.f;
+
+    // LDS addresses are rebuilt per phase from four registers each instead of being kept (the
+    // compiler would hoist all 24 of them out of the loop, and the registers are what limits how far
+    // ahead of the MFMAs the reads can run).  Row read of k-step ks: row r, chunk (2 ks + hh) ^
+    // swz(r): bit b of ks flips chunk bit b + 1, i.e. moves the address by +-(32 << b) bytes with a
+    // sign that is a constant of the lane.  Transposed read of d block db, row pair e: see the
+    // tr_* comments below.  `opaque` keeps the compiler from precomputing the sums.
+    const int xr = swz<DP>(r) ^ hh;
+    const int ra0 = r * (DP * 2) + 16 * xr;
+    const int rd0 = (xr & 2) ? -32 : 32, rd1 = (xr & 4) ? -64 : 64, rd2 = (xr & 8) ? -128 : 128;
+    auto row_addr = [&](const int base, const int ks) __attribute__((always_inline)) {
+        return base + ((ks & 1) ? rd0 : 0) + ((ks & 2) ? rd1 : 0) + ((ks & 4) ? rd2 : 0);
+    };
+    // transposed read (d block db, rows 4 hh + tr_q + 8 e + 16 ks2, chunk 4 db + 2 tr_g + (tr_p >> 1)):
+    //   offset = row * 256 + 64 (db ^ tr_q) + 16 (low ^ ((hh + 2 e) & 3)) + 8 (tr_p & 1),  low = 2 tr_g + (tr_p >> 1)
+    const int tlow = (2 * tr_g + (tr_p >> 1)) ^ hh;
+    const int ta0 = (4 * hh + tr_q) * (DP * 2) + 64 * tr_q + 16 * tlow + 8 * (tr_p & 1);
+    const int te0 = (tr_q & 1) ? -64 : 64, te1 = (tr_q & 2) ? -128 : 128;
+    const int tf = ((tlow & 2) ? -32 : 32) + 8 * (DP * 2);   // e = 1: rows + 8, chunk bit 1 flipped
+    auto opaque = [](int x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); return x; };
+    const int v_base = Cfg::OFF_VT + 32 * wave * (DP * 2);
+
+    // S and dP of sub-block (nx_h, nx_m), read from ring buffer RING
+    auto m_part2 = [&](auto RINGC) __attribute__((always_inline)) {
+        constexpr int RB = RING0 + decltype(RINGC)::value * SL_BYTES, RC = decltype(RINGC)::value * 256;
+        const int q0 = nx_m * 32;
+        skip_nx = false;
+        if (p.is_causal || p.is_local) skip_nx = kw0 >= q0 + 32 + sk - sq + p.wr;
+        if (p.is_local) skip_nx = skip_nx || (kw0 + 32 <= q0 + sk - sq - p.wl);
+        if (has_alibi) alibi_nx = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + hk * p.h_ratio + h_lo + nx_h] / p.scale;
+        if (skip_nx) return;
+        const float *lse_s = (const float *)(smem + RC), *dl_s = lse_s + 32;
+        const int ra = opaque(ra0);
+#ifndef VFA_PP_PFQ
+#define VFA_PP_PFQ 2
+#define VFA_PP_PFD 2
+#endif
+        constexpr int PFQ = VFA_PP_PFQ, PFD = VFA_PP_PFD;   // k-steps the reads run ahead of the MFMAs (S chain, dP chain)
+        i32x4 qa[KS], da[KS], vb[KS], kl[KS];
+        auto rd_q = [&](const int ks) __attribute__((always_inline)) {
+            qa[ks] = *(const i32x4 *)(smem + RB + row_addr(ra, ks));
+            if (ks >= KS - KLDS) kl[ks] = *(const i32x4 *)(smem + kl_base + (ks - (KS - KLDS)) * 1024);
+        };
+#pragma unroll
+        for (int ks = 0; ks < PFQ; ks++) rd_q(ks);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const f32x4 ls = *(const f32x4 *)(lse_s + 8 * g4 + 4 * hh);
+            const f32x4 dl = *(const f32x4 *)(dl_s + 8 * g4 + 4 * hh);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                s[4 * g4 + t] = ls[t];     // (stored as -LSE / scale and -delta: finish_rowc)
+                dp[4 * g4 + t] = dl[t];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks + PFQ < KS) rd_q(ks + PFQ);
+            if (ks + PFD >= KS) {  // the dP chain's first fragments behind the last Q fragments
+                const int k2 = ks + PFD - KS;
+                da[k2] = *(const i32x4 *)(smem + RB + SL_DO + row_addr(ra, k2));
+                vb[k2] = *(const i32x4 *)(smem + v_base + row_addr(ra, k2));
+            }
+            s = mma32<BF16>(qa[ks], ks >= KS - KLDS ? kl[ks] : kf[ks], s);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            if (ks + PFD < KS) {
+                da[ks + PFD] = *(const i32x4 *)(smem + RB + SL_DO + row_addr(ra, ks + PFD));
+                vb[ks + PFD] = *(const i32x4 *)(smem + v_base + row_addr(ra, ks + PFD));
+            }
+            dp = mma32<BF16>(da[ks], vb[ks], dp);
+        }
+        // the same order for the scheduler: first fragments and the 8 row-constant reads, then one
+        // MFMA per k-step with the reads of the k-step PFQ / PFD ahead
+        constexpr int NKL0 = PFQ > KS - KLDS ? PFQ - (KS - KLDS) : 0;   // K fragments among the first PFQ k-steps
+        sched_group<0x100, 8 + PFQ + NKL0>();
+        static_for<0, KS>([&](auto KC) {
+            constexpr int ks = decltype(KC)::value;
+            constexpr int n = (ks + PFQ < KS ? 1 + (ks + PFQ >= KS - KLDS ? 1 : 0) : 0) + (ks + PFD >= KS ? 2 : 0);
+            sched_group<0x100, n>();
+            sched_group<0x008, 1>();
+        });
+        static_for<0, KS>([&](auto KC) {
+            constexpr int ks = decltype(KC)::value;
+            sched_group<0x100, (ks + PFD < KS ? 2 : 0)>();
+            sched_group<0x008, 1>();
+        });
+    };
+    // dV and dK products of sub-block (cur_h, cur_m), transposed reads of ring buffer RING
+    auto m_part1 = [&](auto RINGC) __attribute__((always_inline)) {
+        constexpr int RB = RING0 + decltype(RINGC)::value * SL_BYTES;
+        if (skip_cur) return;
+        const int ta = opaque(ta0);
+        constexpr int NG = 2 * NDB, PF = 2;   // groups (d block, k-step) of 2 MFMAs; read-ahead in groups
+        i32x4 dot[NG], qt[NG];
+        auto rd = [&](const int g) __attribute__((always_inline)) {
+            const int db = g >> 1, ks2 = g & 1;
+            const int o0 = ta + ((db & 1) ? te0 : 0) + ((db & 2) ? te1 : 0) + RB + 16 * ks2 * (DP * 2);
+            const int o1 = o0 + tf;
+            const i32x2 a0 = __builtin_bit_cast(i32x2, lds_read_tr16(smem + SL_DO + o0));
+            const i32x2 a1 = __builtin_bit_cast(i32x2, lds_read_tr16(smem + SL_DO + o1));
+            const i32x2 b0 = __builtin_bit_cast(i32x2, lds_read_tr16(smem + o0));
+            const i32x2 b1 = __builtin_bit_cast(i32x2, lds_read_tr16(smem + o1));
+            dot[g] = i32x4{a0[0], a0[1], a1[0], a1[1]};
+            qt[g] = i32x4{b0[0], b0[1], b1[0], b1[1]};
+        };
+#pragma unroll
+        for (int g = 0; g < PF; g++) rd(g);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (g + PF < NG) rd(g + PF);
+            dv[g >> 1] = mma32<BF16>(dot[g], pf[g & 1], dv[g >> 1]);
+            dk[g >> 1] = mma32<BF16>(qt[g], dsf[g & 1], dk[g >> 1]);
+        }
+        // the order above, imposed on the scheduler (it would otherwise sink every read to just in
+        // front of its MFMA and leave the whole LDS latency exposed): reads PF groups ahead
+        sched_group<0x100, 4 * PF>();
+        static_for<0, NG>([&](auto GC) {
+            constexpr int g = decltype(GC)::value;
+            if constexpr (g + PF < NG) {
+                sched_group<0x100, 2>(); sched_group<0x008, 1>();
+                sched_group<0x100, 2>(); sched_group<0x008, 1>();
+            } else {
+                sched_group<0x008, 2>();
+            }
+        });
+    };
+    // P and dS of sub-block (cur_h, cur_m) from its S and dP (forward's mask and bias)
+    auto v_phase = [&]() __attribute__((always_inline)) {
+        if (skip_cur) return;
+        const int q0 = cur_m * 32;
+        const int col = kw0 + r;
+        const bool masked_tile = has_alibi || (kw0 + 32 > sk) || (q0 + 32 > sq) ||
+                                 ((p.is_causal || p.is_local) && (kw0 + 32 > q0 + 1 + sk - sq + p.wr)) ||
+                                 (p.is_local && (kw0 < q0 + 31 + sk - sq - p.wl));
+        if (masked_tile) {  // (the arithmetic of the step loop below)
+            constexpr int BIG = 1 << 28;
+            const int shift = q0 + 4 * hh + sk - sq;
+            int lo_r = (p.is_causal || p.is_local) ? col - shift - p.wr : -BIG;
+            int hi_r = p.is_local ? col - shift + p.wl : BIG;
+            hi_r = min(hi_r, sq - q0 - 4 * hh - 1);
+            lo_r = max(lo_r, -BIG);
+            if (col >= sk || hi_r < lo_r) { lo_r = BIG; hi_r = BIG; }
+            const unsigned span = (unsigned)(hi_r - lo_r);
+            if (has_alibi) {
+                if (p.is_causal) {
+                    const float ab = alibi_cur * (float)col;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) s[j] += ab;
+                } else {
+                    const int dc = shift - col;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) s[j] -= alibi_cur * fabsf((float)((j & 3) + 8 * (j >> 2) + dc));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int roff = (j & 3) + 8 * (j >> 2);
+                s[j] = ((unsigned)(roff - lo_r) <= span) ? s[j] : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int j = 8 * ks2 + 2 * w;
+                const float p0 = __builtin_amdgcn_exp2f(s[j] * c2), p1 = __builtin_amdgcn_exp2f(s[j + 1] * c2);
+                pf[ks2][w] = pack2<BF16>(p0, p1);
+                dsf[ks2][w] = pack2<BF16>(p0 * dp[j], p1 * dp[j + 1]);
+            }
+    };
+
+#ifdef VFA_STAMP
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
+    if (grp_b) {
+        issue(I0{}); issue(I1{});
+        wait_keep(I1{});
+        finish_rowc(I0{});
+    }
+    phase_barrier();                 // slice 0 is in LDS
+    if (grp_b) phase_barrier();      // waves 4-7 run one phase behind
+    m_part2(I0{});
+    if (grp_b) {
+        wait_keep(I0{});             // slice 1
+        finish_rowc(I1{});
+    }
+    phase_barrier();
+    skip_cur = skip_nx; alibi_cur = alibi_nx;
+    advance(nx_h, nx_m);
+    // One sub-block: u is its index, RING = u % 3 the buffer it sits in.  Slice u + 2 goes into
+    // the buffer of slice u - 1, whose last reader (a wave of 4-7 in M(u - 1)) is done when the
+    // barrier in front of this point has been passed; it is waited for a phase pair later, at the
+    // end of M(u), one barrier ahead of its first reader (a wave of 0-3 in M(u + 1)).
+    auto sub_block = [&](const int u, auto RINGC) __attribute__((always_inline)) {
+        constexpr int RING = decltype(RINGC)::value;
+        using RN = std::integral_constant<int, (RING + 1) % NRING>;   // sub-block u + 1
+        using RI = std::integral_constant<int, (RING + 2) % NRING>;   // sub-block u + 2 (requested now)
+        STAMP(7);
+        if (grp_b) issue(RI{});
+        STAMP(0);
+        v_phase();
+        STAMP(1);
+        phase_barrier();
+        STAMP(2);
+        __builtin_amdgcn_s_setprio(VFA_PP_PRIO);   // the matrix phase wins the issue arbitration against the partner's vector work
+        m_part1(RINGC);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(3);
+        if (u + 1 < T) m_part2(RN{});
+        STAMP(4);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp_b) {
+            wait_keep(I0{});
+            finish_rowc(RI{});
+        }
+        phase_barrier();
+        STAMP(5);
+        cur_h = nx_h; cur_m = nx_m; skip_cur = skip_nx; alibi_cur = alibi_nx;
+        advance(nx_h, nx_m);
+    };
+    for (int u = 0;;) {
+        sub_block(u, I0{}); if (++u >= T) break;
+        sub_block(u, I1{}); if (++u >= T) break;
+        sub_block(u, I2{}); if (++u >= T) break;
+    }
+#ifdef VFA_STAMP
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long *dst = g_stamps_dkdv + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 7; i++) dst[i] = acc_[i];
+        dst[7] = (unsigned long long)T;
+    }
+#endif
+    if (!grp_b) phase_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the out-of-range requests still write (zeros) into the ring
+    }  // T > 0
+    }  // PP
+    if constexpr (!PP) {
     // ---- Q / dO slice staging (register prefetch, two LDS buffers) ----
     float rowc = 0.f;  // lse (tid < QM) or delta (QM <= tid < 2 QM) of the slice
     // From d = 128 the slice carries -LSE / scale and the S accumulator starts from it, so that
@@ -615,6 +1006,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         dst[7] = (unsigned long long)total_steps;
     }
 #endif
+    }  // !PP
 
     if constexpr (HS) {
         // fp32 partials straight from the accumulators: lane (r, hh) holds, per d block and group
@@ -731,14 +1123,14 @@ static bool bwd_fits_buffer(const KParams &p) {
     return rq * p.q_rs * 2 < lim && rq * p.do_rs * 2 < lim && rk * p.k_rs * 2 < lim && rk * p.v_rs * 2 < lim;
 }
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false>
 static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
     using Cfg = BwdCfg<DP, NW>;
-    constexpr int LDS = Cfg::LDS_BYTES + (DROP ? NW * 1024 : 0);  // + the Philox exchange space
+    constexpr int LDS = PP ? Cfg::PP_LDS_BYTES : Cfg::LDS_BYTES + (DROP ? NW * 1024 : 0);  // + the Philox exchange space
     const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS>;
+    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS, PP>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, LDS, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(HS ? p.hsplit : 1)), dim3(Cfg::NT), LDS,
@@ -748,6 +1140,20 @@ static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
 
 template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
 static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
+    if constexpr (FAST && DP == 128 && NW == 8 && !DROP) {
+        // the two-phase schedule (PP in bwd_dkdv_kernel); development switch 0: 3 = always, 4 = never
+        // Opt-in: measured level with the default schedule (2.12 vs 2.12 ms on b8 s4096 h32 d128
+        // causal, 1.79 vs 1.80 ms on all-zero inputs): beside a partner's vector work the MFMAs
+        // issue every ~43 cycles instead of 32, which costs what the overlap saves.
+        const bool pp_wanted = g_tuning[0] == 3 || (g_tuning[0] != 4 && VFA_DKDV_PP_DEFAULT);
+        // (its loads address a head as the batch entry's base plus a 32-bit byte offset)
+        const int64_t lim = (int64_t)1 << 32;
+        const bool pp = pp_wanted && (int64_t)p.h * p.q_hs * 2 < lim && (int64_t)p.h * p.do_hs * 2 < lim &&
+                        (int64_t)p.h * p.seqlen_q_rounded * 4 < lim;
+        if (pp)
+            return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true, true>(p, stream)
+                                : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false, true>(p, stream);
+    }
     return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true>(p, stream)
                         : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false>(p, stream);
 }

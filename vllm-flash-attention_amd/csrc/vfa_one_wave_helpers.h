@@ -34,6 +34,30 @@ __device__ __forceinline__ void dma_16b_to_lds(const i32x4 rsrc, const unsigned 
                  "buffer_load_dwordx4 %2, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(rsrc), "v"(voff), "s"(lds_addr) : "memory");
 }
+// The same with 4 bytes per lane: lane L writes dword L of the 256 bytes at `lds_addr`, whatever the
+// set of active lanes is.
+__device__ __forceinline__ void dma_4b_to_lds(const i32x4 rsrc, const unsigned voff, const unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "buffer_load_dword %2, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(rsrc), "v"(voff), "s"(lds_addr) : "memory");
+}
+// Four 16-byte-per-lane loads (two per descriptor) in one statement, M0 saved and restored once.
+__device__ __forceinline__ void dma_16b_x4_to_lds(const i32x4 ra, const unsigned va0, const unsigned va1,
+                                                  const unsigned la0, const unsigned la1, const i32x4 rb,
+                                                  const unsigned vb0, const unsigned vb1, const unsigned lb0,
+                                                  const unsigned lb1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %1, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %6, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %6, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(ra), "v"(va0), "v"(va1), "s"(la0), "s"(la1), "s"(rb), "v"(vb0), "v"(vb1), "s"(lb0), "s"(lb1)
+                 : "memory");
+}
 // 128-bit buffer descriptor (raw buffer, no stride, `bytes` records of one byte) in scalar registers.
 __device__ __forceinline__ i32x4 make_rsrc(const void *base, const unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
