@@ -771,7 +771,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     auto store_rowc = [&](int buf) {
         char *qb = smem + Cfg::OFF_Q + buf * Cfg::QBUF_BYTES;
         if (tid < 2 * BW_QM)
-            ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = (LSE_IN_ACC && tid < BW_QM) ? -rowc / p.scale : rowc;
+            // delta is stored negated: the dP accumulator starts from it as it is read
+            ((float *)(qb + 2 * Cfg::QT_BYTES))[tid] = tid >= BW_QM ? -rowc : (LSE_IN_ACC ? -rowc / p.scale : rowc);
     };
     auto store_slice = [&](int buf) {
         if constexpr (!SPLIT) {
@@ -920,7 +921,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         for (int g4 = 0; g4 < 4; g4++) {
             const f32x4 dl = *(const f32x4 *)(dl_s + 8 * g4 + 4 * hh);
 #pragma unroll
-            for (int t = 0; t < 4; t++) dp[4 * g4 + t] = -dl[t];
+            for (int t = 0; t < 4; t++) dp[4 * g4 + t] = dl[t];   // (-delta)
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
@@ -945,8 +946,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                 if constexpr (DROP) {
                     // dropped entries: no contribution to dV, and dP' = -delta (dP masked to 0)
                     const bool k0 = (keep >> j) & 1u, k1 = (keep >> (j + 1)) & 1u;
-                    const float nd0 = -dl_s[8 * (j >> 2) + 4 * hh + (j & 3)];
-                    const float nd1 = -dl_s[8 * (j >> 2) + 4 * hh + (j & 3) + 1];
+                    const float nd0 = dl_s[8 * (j >> 2) + 4 * hh + (j & 3)];
+                    const float nd1 = dl_s[8 * (j >> 2) + 4 * hh + (j & 3) + 1];
                     pf[ks2][w] = pack2<BF16>(k0 ? s[j] : 0.f, k1 ? s[j + 1] : 0.f);
                     dsf[ks2][w] = pack2<BF16>(s[j] * (k0 ? dp[j] : nd0), s[j + 1] * (k1 ? dp[j + 1] : nd1));
                 } else {
@@ -1352,6 +1353,13 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
             }
         }
         const float lse2 = lse_r * (float)M_LOG2E;
+        constexpr bool NDL_BLOCK = DP <= 128;   // (at d = 256 the registers are not there)
+        f32x16 ndl;
+        if constexpr (NDL_BLOCK) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) ndl[j] = -dl_r;
+            asm volatile("" : "+v"(ndl));  // (kept as 16 registers: not rebuilt from dl_r at every use)
+        }
         unsigned long long ph_seed = 0, ph_off = 0;
         if constexpr (DROP) {
             ph_seed = p.rng_read ? p.rng_state[0] : p.philox_seed;
@@ -1397,12 +1405,17 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
                 // S^T and dP'^T = V dO^T - delta for 32 keys; the query is on the lane
                 f32x16 s, dp;
 #pragma unroll
-                for (int j = 0; j < 16; j++) { s[j] = 0.f; dp[j] = -dl_r; }
+                for (int j = 0; j < 16; j++) {
+                    s[j] = 0.f;
+                    if constexpr (!NDL_BLOCK) dp[j] = -dl_r;
+                }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     const int off = lds_off<DP>(32 * kb2 + r, 2 * ks + hh);
                     s = mma32<BF16>(*(const i32x4 *)(kb + off), qf[ks], s);
-                    dp = mma32<BF16>(*(const i32x4 *)(vb + off), dof[ks], dp);
+                    // the dP chain starts from the block of -delta (kept for the whole kernel:
+                    // filling the accumulator anew would be 16 moves per 32 keys)
+                    dp = mma32<BF16>(*(const i32x4 *)(vb + off), dof[ks], (NDL_BLOCK && ks == 0) ? ndl : dp);
                 }
                 if (need) {
                     const int row = q0w + r;
