@@ -10,7 +10,9 @@ import torch
 import cabi
 import bench
 
-SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 8192, 32, 8, 128, True)]
+SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 8192, 32, 8, 128, True),
+          (4, 2048, 16, 16, 64, True), (32, 512, 16, 16, 128, True), (16, 1024, 16, 16, 128, False),
+          (8, 2048, 32, 32, 64, False)]
 
 
 def main():
@@ -28,8 +30,12 @@ def main():
             k, v = a.split("=", 1)[1].split(":")
             handles[-1].vfa_debug_set_tuning(int(k), int(v))
     stream = torch.cuda.current_stream().cuda_stream
-    for b, s, h, hk, d, causal in SHAPES:
-        for data in ("random", "zeros"):
+    only = [int(a) for a in sys.argv[1:] if a.isdigit()]
+    datas = ("random",) if "--random-only" in sys.argv else ("random", "zeros")
+    for si, (b, s, h, hk, d, causal) in enumerate(SHAPES):
+        if only and si not in only:
+            continue
+        for data in datas:
             torch.manual_seed(0)
             mk = torch.randn if data == "random" else torch.zeros
             q = mk(b, s, h, d, device="cuda", dtype=torch.bfloat16)
@@ -51,7 +57,7 @@ def main():
             flops = 4.0 * b * h * s * s * d * (0.5 if causal else 1.0)
             for i, p in enumerate(libs):
                 t = sorted(times[i])[len(times[i]) // 2]
-                print(f"b{b} s{s} h{h}/{hk} causal={causal} {data:6s} {os.path.basename(p):26s} {t:.3f} ms {flops / t / 1e9:.0f} TF", flush=True)
+                print(f"b{b} s{s} h{h}/{hk} d{d} causal={causal} {data:6s} {os.path.basename(p):26s} {t:.3f} ms {flops / t / 1e9:.0f} TF", flush=True)
 
 
 if __name__ == "__main__":
