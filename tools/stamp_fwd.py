@@ -10,7 +10,10 @@ import cabi
 cabi.LIB_PATH = os.path.join(ROOT, "vllm-flash-attention_amd", "libvfa_hip_stamp.so")
 lib = cabi.lib()
 causal = len(sys.argv) > 1 and sys.argv[1] == "causal"
-q = torch.randn(8, 4096, 32, 128, device="cuda", dtype=torch.bfloat16)
+# optional shape: stamp_fwd.py [causal] b s h d   (4-wave blocks fill waves 0-3 of the table only)
+dims = [int(x) for x in sys.argv[1:] if x.isdigit()]
+b_, s_, h_, d_ = dims if len(dims) == 4 else (8, 4096, 32, 128)
+q = torch.randn(b_, s_, h_, d_, device="cuda", dtype=torch.bfloat16)
 k = torch.randn_like(q); v = torch.randn_like(q)
 for _ in range(3):
     cabi.fwd(q, k, v, causal=causal)
@@ -25,5 +28,7 @@ tiles = a[:, :, 7]
 sel = tiles > 0
 print("blocks with data:", int(sel[:, 0].sum()))
 for w in (0, 3, 4, 7):
+    if not sel[:, w].any():
+        continue
     per = [a[sel[:, w], w, i].sum() / tiles[sel[:, w], w].sum() for i in range(7)]
     print(f"wave {w}: " + "  ".join(f"{names[i]}={per[i]:.0f}" for i in range(7)))

@@ -120,7 +120,14 @@ template <int DP, int NW>
 struct BwdCfg {
     static constexpr int NT = NW * 64;
     static constexpr int KB = NW * 32;                        // keys per workgroup
-    static constexpr bool V_IN_LDS = NW == 8;
+    static constexpr bool V_IN_LDS = NW == 8 || DP == 256;
+    // d = 256: the dK / dV accumulators of 32 keys x 256 columns are 256 registers, the whole
+    // accumulation half of the register file; with S, dP and the K fragments beside them the
+    // compiler moves tiles between the register files and scratch all through the step (measured:
+    // 111 TFLOP/s backward).  The head dim is therefore cut in DSPLIT column halves, each taken by
+    // its own workgroup (blockIdx.z): S and dP are computed in both (12 instead of 8 products per
+    // key block and query slice), the accumulators are 128 registers and nothing spills.
+    static constexpr int DSPLIT = DP == 256 ? 2 : 1;
     static constexpr int CPR = DP / 8;
     static constexpr int KV_BYTES = KB * DP * 2;              // one of K / V
     // Sub-blocks per slice, 8-wave kernel: 2 (measured on MI355X: +29 % at d = 64, +4 % at d = 128,
@@ -152,7 +159,8 @@ __global__ void __launch_bounds__(NW * 64, 1)
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
     constexpr int CPR = Cfg::CPR, NT = Cfg::NT, KB = Cfg::KB;
-    constexpr int KS = DP / 16, NDB = DP / 32;
+    constexpr int KS = DP / 16, NDB = DP / 32 / Cfg::DSPLIT;   // NDB: 32-column blocks of dK / dV held by this workgroup
+    const int db0 = Cfg::DSPLIT > 1 ? (int)blockIdx.z * NDB : 0;   // its first block
     constexpr int QCH = Cfg::QCH, BW_QM = Cfg::QM, QSUB = Cfg::QSUB;
     constexpr bool V_IN_LDS = Cfg::V_IN_LDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -962,7 +970,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ks2++) {
                 const int row0 = 16 * ks2 + 4 * hh + tr_q;
-                const int ch = 4 * db + 2 * tr_g + (tr_p >> 1);
+                const int ch = 4 * (db0 + db) + 2 * tr_g + (tr_p >> 1);
                 const int o0 = lds_off<DP>(row0, ch) + 8 * (tr_p & 1);
                 const int o1 = lds_off<DP>(row0 + 8, ch) + 8 * (tr_p & 1);
                 const i32x2 a0 = __builtin_bit_cast(i32x2, lds_read_tr16(dob + o0));
@@ -1021,7 +1029,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             for (int db = 0; db < NDB; db++)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++) {
-                    const int col = 32 * db + 8 * g4 + 4 * hh;
+                    const int col = 32 * (db0 + db) + 8 * g4 + 4 * hh;
                     if (col < p.d) {
                         *(f32x4 *)(p.dk_part + off + col) = f32x4{dk[db][4 * g4] * p.scale_rp, dk[db][4 * g4 + 1] * p.scale_rp,
                                                                   dk[db][4 * g4 + 2] * p.scale_rp, dk[db][4 * g4 + 3] * p.scale_rp};
@@ -1053,15 +1061,16 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                     w2[0] = pack2<BF16>(dv[db][4 * g4] * rp, dv[db][4 * g4 + 1] * rp);
                     w2[1] = pack2<BF16>(dv[db][4 * g4 + 2] * rp, dv[db][4 * g4 + 3] * rp);
                 }
-                *(i32x2 *)(ob + r * Cfg::OUT_ROWB + (32 * db + 8 * g4 + 4 * hh) * 2) = w2;
+                *(i32x2 *)(ob + r * Cfg::OUT_ROWB + (32 * (db0 + db) + 8 * g4 + 4 * hh) * 2) = w2;
             }
         __syncthreads();
         unsigned short *dst = which == 0 ? dkg : dvg;
         const int64_t rs = which == 0 ? p.dk_rs : p.dv_rs;
+        constexpr int CPRW = CPR / Cfg::DSPLIT;   // chunks of a row that this workgroup holds
 #pragma unroll
-        for (int i = 0; i < (32 * CPR) / 64; i++) {
+        for (int i = 0; i < (32 * CPRW) / 64; i++) {
             const int c = lane + 64 * i;
-            const int row = c / CPR, ch = c % CPR;
+            const int row = c / CPRW, ch = c % CPRW + 4 * db0;
             const i32x4 w = *(const i32x4 *)(ob + row * Cfg::OUT_ROWB + ch * 16);
             if (kw0 + row < sk && ch * 8 < p.d) *(i32x4 *)(dst + (int64_t)(kw0 + row) * rs + ch * 8) = w;
         }
@@ -1134,7 +1143,7 @@ static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
     auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS, PP>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, LDS, lds_set); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(HS ? p.hsplit : 1)), dim3(Cfg::NT), LDS,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(HS ? p.hsplit : 1), (unsigned)Cfg::DSPLIT), dim3(Cfg::NT), LDS,
                        stream, p, n_kblocks);
     return hipGetLastError();
 }
