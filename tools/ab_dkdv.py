@@ -19,7 +19,9 @@ def main():
     shapes = [(8, 4096, 32, 32, 128, True, "bf16"), (8, 4096, 32, 32, 128, False, "bf16"),
               (4, 4096, 32, 8, 128, True, "bf16"), (2, 8192, 16, 16, 128, True, "bf16"),
               (16, 1024, 16, 16, 128, True, "bf16"), (32, 512, 16, 16, 128, True, "bf16"),
-              (4, 2048, 16, 16, 64, True, "bf16"), (8, 4096, 32, 32, 64, True, "bf16")]
+              (4, 2048, 16, 16, 64, True, "bf16"), (8, 4096, 32, 32, 64, True, "bf16"),
+              (4, 4096, 16, 16, 256, True, "bf16"), (4, 4096, 16, 16, 256, False, "bf16"),
+              (4, 4096, 16, 16, 192, True, "bf16")]
     variants = [1, 2]   # development switch 0: 1 = 8 waves x 32 keys, 2 = 4 waves x 64 keys, 3 = two-phase 8 waves
     args = sys.argv[1:]
     zeros = "--zeros" in args   # all-zero inputs: same instruction stream, no data-dependent power

@@ -680,7 +680,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction in lane order, each lane fetching
     // the chunk the XOR swizzle places at its slot): no staging registers and no ds_write.
     // Measured on MI355X: -5..7 % kernel time at d = 128, +8 % at d = 64 (kept on registers).
-    constexpr bool DIRECT = FAST && DP == 128;
+    constexpr bool DIRECT = FAST && (DP == 128 || DP == 256);
     constexpr bool SPLIT = !DIRECT && QCH == 2 && QSUB == 2;
     constexpr int NSTG = SPLIT ? 1 : QCH;  // staging register sets
     i32x4 qreg[NSTG], doreg[NSTG];
@@ -708,14 +708,24 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     };
     constexpr int RPI = 64 / CPR;                               // rows per wave instruction
     constexpr int NI = DIRECT ? BW_QM / (RPI * NW) : 1;         // instructions per wave, slice, tensor
-    static_assert(!DIRECT || (BW_QM % (RPI * NW) == 0 && (RPI * NW) % 16 == 0), "direct slice loads");
-    unsigned dq_voff = 0, ddo_voff = 0;
+    // The rows of a wave's instructions are RPI * NW apart: a multiple of 16 keeps the swizzle of
+    // the lane's row (one offset serves all instructions); 8 rows apart (d = 256, 4 waves) it
+    // alternates between two values, one for the even and one for the odd instructions.
+    constexpr int NVAR = (RPI * NW) % 16 == 0 ? 1 : 2;
+    static_assert(!DIRECT || (BW_QM % (RPI * NW) == 0 && (RPI * NW) % 8 == 0), "direct slice loads");
+    unsigned dq_voff = 0, ddo_voff = 0, dq_voff1 = 0, ddo_voff1 = 0;   // (the ...1 pair: odd instructions, NVAR = 2)
     if constexpr (DIRECT) {
         const int row0 = RPI * wave + lane / CPR;
         const int ch = (lane % CPR) ^ swz<DP>(row0);
         const bool ok = ch * 8 < p.d;
         dq_voff = ok ? (unsigned)((row0 * (int)p.q_rs + ch * 8) * 2) : 0x80000000u;
         ddo_voff = ok ? (unsigned)((row0 * (int)p.do_rs + ch * 8) * 2) : 0x80000000u;
+        if constexpr (NVAR == 2) {
+            const int ch1 = (lane % CPR) ^ swz<DP>(row0 + RPI * NW);
+            const bool ok1 = ch1 * 8 < p.d;
+            dq_voff1 = ok1 ? (unsigned)((row0 * (int)p.q_rs + ch1 * 8) * 2) : 0x80000000u;
+            ddo_voff1 = ok1 ? (unsigned)((row0 * (int)p.do_rs + ch1 * 8) * 2) : 0x80000000u;
+        }
     }
     auto load_slice_direct = [&](const int gh, const int m, const int buf) __attribute__((always_inline)) {
         if constexpr (DIRECT) {
@@ -732,9 +742,9 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             for (int i = 0; i < NI; i++) {
                 const unsigned rows = (unsigned)(q0 + RPI * NW * i);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lds_ptr)(qb + (wave + NW * i) * 1024), 16,
-                                                         dq_voff + rows * (unsigned)p.q_rs * 2, 0, 0, 0);
+                                                         ((NVAR == 2 && (i & 1)) ? dq_voff1 : dq_voff) + rows * (unsigned)p.q_rs * 2, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, (lds_ptr)(qb + Cfg::QT_BYTES + (wave + NW * i) * 1024), 16,
-                                                         ddo_voff + rows * (unsigned)p.do_rs * 2, 0, 0, 0);
+                                                         ((NVAR == 2 && (i & 1)) ? ddo_voff1 : ddo_voff) + rows * (unsigned)p.do_rs * 2, 0, 0, 0);
             }
         }
     };
@@ -1172,8 +1182,6 @@ template <int DP, bool BF16, int NW, bool DROP>
 static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
     if constexpr (DROP) {  // one variant (generic loads) per geometry
         return launch_dkdv_impl<DP, BF16, NW, false, true>(p, stream);
-    } else if constexpr (DP == 256) {  // no registers to spare for the buffer-load offsets
-        return launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
     } else {
         return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
                                   : launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
