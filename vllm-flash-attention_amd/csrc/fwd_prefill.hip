@@ -206,14 +206,23 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     // step between a wave's instructions (a multiple of 16 rows at these head dims)
     constexpr int RPI = 64 / CPR;                    // rows per wave instruction
     constexpr int NI = DIRECT ? BN / (RPI * NW) : 1;  // instructions per wave, tile and tensor
-    static_assert(!DIRECT || (DP <= 128 && BN % (RPI * NW) == 0), "direct LDS loads: head dim <= 128");
-    unsigned dk_voff = 0, dv_voff = 0;
+    // (rows RPI * NW apart: a multiple of 16 keeps the lane's swizzle; 8 apart -- d = 256 with 4
+    //  waves -- it alternates between two values, for the even and the odd instructions)
+    constexpr int NVAR = (RPI * NW) % 16 == 0 ? 1 : 2;
+    static_assert(!DIRECT || (BN % (RPI * NW) == 0 && (RPI * NW) % 8 == 0), "direct LDS loads");
+    unsigned dk_voff = 0, dv_voff = 0, dk_voff1 = 0, dv_voff1 = 0;
     if constexpr (DIRECT) {
         const int row0 = RPI * wave + lane / CPR;
         const int ch = (lane % CPR) ^ swz<DP>(row0);
         const bool ok = ch * 8 < p.d;
         dk_voff = ok ? (unsigned)((row0 * (int)p.k_rs + ch * 8) * 2) : 0x80000000u;
         dv_voff = ok ? (unsigned)((row0 * (int)p.v_rs + ch * 8) * 2) : 0x80000000u;
+        if constexpr (NVAR == 2) {
+            const int ch1 = (lane % CPR) ^ swz<DP>(row0 + RPI * NW);
+            const bool ok1 = ch1 * 8 < p.d;
+            dk_voff1 = ok1 ? (unsigned)((row0 * (int)p.k_rs + ch1 * 8) * 2) : 0x80000000u;
+            dv_voff1 = ok1 ? (unsigned)((row0 * (int)p.v_rs + ch1 * 8) * 2) : 0x80000000u;
+        }
     }
     auto load_tile_direct = [&](int n, auto BUFC) __attribute__((always_inline)) {
         constexpr int BUF = decltype(BUFC)::value;
@@ -224,10 +233,10 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 const unsigned rows = (unsigned)(n * BN + RPI * NW * i);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     k_rsrc, (lds_ptr)(smem + BUF * Cfg::TILE_BYTES + (wave + NW * i) * 1024), 16,
-                    dk_voff + rows * k_rs2, 0, 0, 0);
+                    ((NVAR == 2 && (i & 1)) ? dk_voff1 : dk_voff) + rows * k_rs2, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     v_rsrc, (lds_ptr)(smem + (2 + BUF) * Cfg::TILE_BYTES + (wave + NW * i) * 1024), 16,
-                    dv_voff + rows * v_rs2, 0, 0, 0);
+                    ((NVAR == 2 && (i & 1)) ? dv_voff1 : dv_voff) + rows * v_rs2, 0, 0, 0);
             }
         }
     };
@@ -728,7 +737,7 @@ template <int DP, bool BF16, int NW>
 static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     // contiguous K/V: straight into LDS where the lane map allows it (measured on MI355X against
     // register staging: +2..4 % at seqlen 4096, +9 % at 512..2048, d = 64 +4 %)
-    if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, DP <= 128 ? 3 : 1>(p, stream);
+    if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, 3>(p, stream);
     if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2>(p, stream);
     return launch_prefill_impl<DP, BF16, NW, 0>(p, stream);
 }
@@ -768,7 +777,7 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
 // Split-KV variants (4 waves; contiguous or buffer-paged K/V), a translation unit of their own.
 template <int DP, bool BF16>
 static hipError_t launch_prefill_split(const KParams &p, hipStream_t stream) {
-    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, DP <= 128 ? 3 : 1, false, true>(p, stream)
+    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, 3, false, true>(p, stream)
                              : launch_prefill_impl<DP, BF16, 4, 2, false, true>(p, stream);
 }
 // Whether the split variants can load this K/V layout (else the caller takes the decode kernel).
