@@ -242,7 +242,9 @@ def test_block_order_covers_every_block(b, h, hk, sq, sk, d, causal):
 
 
 @pytest.mark.parametrize("b,h,hk,sq,sk,d,varlen", [(1, 8, 1, 300, 520, 128, False), (2, 6, 2, 257, 257, 64, False),
-                                                  (1, 4, 2, 100, 700, 128, True), (1, 16, 4, 1030, 1030, 128, False)])
+                                                  (1, 4, 2, 100, 700, 128, True), (1, 16, 4, 1030, 1030, 128, False),
+                                                  # d > 128: two workgroups per key block, one per half of the head dim
+                                                  (1, 8, 2, 300, 520, 256, False), (1, 4, 2, 100, 391, 192, True)])
 @pytest.mark.parametrize("causal", [True, False])
 def test_bwd_head_split_matches_unsplit_and_oracle(b, h, hk, sq, sk, d, varlen, causal):
     """Few (batch, kv head) pairs: the heads of a KV group are swept by several workgroups per key
