@@ -187,14 +187,30 @@ def test_varlen_paged_vs_oracle():
 
 
 @pytest.mark.parametrize("d,page,sq", [(128, 16, 300), (128, 64, 700), (128, 256, 4200), (128, 32, 4200),
-                                       (64, 32, 500), (64, 16, 500), (256, 16, 260), (128, 48, 300)])
+                                       (64, 32, 500), (64, 16, 500), (256, 16, 260), (128, 48, 300),
+                                       (192, 16, 300), (96, 32, 300), (40, 16, 200), (256, 64, 700),
+                                       (64, 128, 700), (224, 128, 4200)])
 @pytest.mark.parametrize("causal", [False, True])
-def test_varlen_paged_prefill_equals_contiguous(d, page, sq, causal):
+@pytest.mark.parametrize("staged", [False, True])
+def test_varlen_paged_prefill_equals_contiguous(d, page, sq, causal, staged):
     """Prefill over a paged cache must give the bits of the same call on contiguous K/V: covers the
-    per-page buffer-descriptor loads (power-of-two pages holding whole load rounds) and the
-    per-row path (small or odd pages), ragged lengths that end inside a page, NaN in every cache
-    row past a sequence's end and in unused pages, and garbage in unused block-table entries."""
+    per-page buffer-descriptor loads (power-of-two pages of at least 16 rows; straight into LDS, or
+    with development switch 5 = 1 through registers where a page holds whole load rounds) and the
+    per-row path (small or odd pages), head dims below the padded one (whose padding chunks are
+    redirected to real ones), ragged lengths that end inside a page, NaN in every cache row past a
+    sequence's end and in unused pages, and garbage in unused block-table entries."""
     import vllm_flash_attn as fa
+    import cabi
+    if staged and (d > 128 or page % 16 or page & (page - 1)):
+        pytest.skip("register staging is an alternative only for d <= 128 and power-of-two pages")
+    cabi.lib().vfa_debug_set_tuning(5, 1 if staged else 0)
+    try:
+        _paged_prefill_equals_contiguous(fa, d, page, sq, causal)
+    finally:
+        cabi.lib().vfa_debug_set_tuning(5, 0)
+
+
+def _paged_prefill_equals_contiguous(fa, d, page, sq, causal):
     torch.manual_seed(d + page)
     h, hk = 4, 2
     kl = [sq, sq - page // 2 - 3, 37]

@@ -48,10 +48,10 @@ def main():
         del kp, vp
 
 
-def prefill_paged():
+def prefill_paged(d=128):
     """Causal prefill over a paged cache (flash_attn_varlen_func + block_table) vs contiguous K/V."""
     torch.manual_seed(0)
-    b, s, h, hk, d = 8, 4096, 32, 8, 128
+    b, s, h, hk = (8, 4096, 32, 8) if d <= 128 else (4, 4096, 16, 4)
     dt = torch.bfloat16
     q = torch.randn(b * s, h, d, device="cuda", dtype=dt)
     k = torch.randn(b * s, hk, d, device="cuda", dtype=dt)
@@ -61,6 +61,7 @@ def prefill_paged():
     t = med_ms(lambda: fa.flash_attn_varlen_func(q, k, v, cu, cu, s, s, causal=True))
     ref = fa.flash_attn_varlen_func(q, k, v, cu, cu, s, s, causal=True)
     print(f"prefill contiguous: {t:.3f} ms  {flops / t / 1e9:.0f} TF", flush=True)
+    import cabi
     for page in (16, 256):
         nb = b * s // page
         perm = torch.randperm(nb, device="cuda")
@@ -70,9 +71,12 @@ def prefill_paged():
         kp[perm] = k.view(nb, page, hk, d)
         vp[perm] = v.view(nb, page, hk, d)
         f = lambda: fa.flash_attn_varlen_func(q, kp, vp, cu, cu, s, s, causal=True, block_table=bt)
-        t = med_ms(f)
-        err = (f().float() - ref.float()).abs().max().item()
-        print(f"prefill paged, page {page}: {t:.3f} ms  {flops / t / 1e9:.0f} TF  (max diff {err:.1e})", flush=True)
+        for sw in (0, 1):   # development switch 5: 1 = paged tiles straight into LDS at every head dim
+            cabi.lib().vfa_debug_set_tuning(5, sw)
+            t = med_ms(f)
+            err = (f().float() - ref.float()).abs().max().item()
+            print(f"prefill paged, page {page}, switch {sw}: {t:.3f} ms  {flops / t / 1e9:.0f} TF  (max diff {err:.1e})", flush=True)
+        cabi.lib().vfa_debug_set_tuning(5, 0)
 
 
 def small_batch():
@@ -93,7 +97,7 @@ def small_batch():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "prefill":
-        prefill_paged()
+        prefill_paged(int(sys.argv[2]) if len(sys.argv) > 2 else 128)
     elif len(sys.argv) > 1 and sys.argv[1] == "small":
         small_batch()
     else:

@@ -92,6 +92,10 @@ struct PrefillCfg {
 // the workgroup's threads cover per load round: the rows of one round then lie in ONE page, its
 // id is a scalar, and the round is a buffer load through a descriptor built (in scalar registers)
 // at that page's rows and ending at the page's or the sequence's last row.
+// LD = 4: paged K/V whose page size is a power of two (and a multiple of 16 rows, as the API
+// requires), written to LDS directly like LD = 3: each wave fills BN / NW consecutive rows of the
+// tile, in groups of at most 16 rows that lie in one page and share a descriptor.  The variant the
+// launcher takes for paged K/V (LD = 2 remains behind a development switch).
 // LD = 3: as LD = 1, but the buffer loads write LDS directly (buffer_load_dwordx4 ... lds): a wave
 // instruction fills 1 KiB of LDS in lane order, so each lane fetches the global chunk that the
 // XOR swizzle places at its slot.  No staging registers, no ds_write, and the wave does not wait
@@ -110,7 +114,9 @@ template <int DP, bool BF16, int NW, int LD, bool DROP, bool SPLIT = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     constexpr bool DIRECT = LD == 3;                 // contiguous K/V, loaded straight into LDS
-    constexpr bool FAST = LD == 1 || DIRECT, PAGED_BUF = LD == 2;
+    constexpr bool PDIRECT = LD == 4;                // paged K/V (per-page descriptors), loaded straight into LDS
+    constexpr bool TO_LDS = DIRECT || PDIRECT;
+    constexpr bool FAST = LD == 1 || DIRECT, PAGED_BUF = LD == 2 || PDIRECT;
     using Cfg = PrefillCfg<DP, BF16, NW>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
     constexpr int KS = DP / 16;   // k-steps of QK^T
@@ -205,12 +211,27 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     // DIRECT: lane -> (row, chunk) of its LDS slot; the swizzle of a row is unchanged by the row
     // step between a wave's instructions (a multiple of 16 rows at these head dims)
     constexpr int RPI = 64 / CPR;                    // rows per wave instruction
-    constexpr int NI = DIRECT ? BN / (RPI * NW) : 1;  // instructions per wave, tile and tensor
+    constexpr int NI = TO_LDS ? BN / (RPI * NW) : 1;  // instructions per wave, tile and tensor
     // (rows RPI * NW apart: a multiple of 16 keeps the lane's swizzle; 8 apart -- d = 256 with 4
     //  waves -- it alternates between two values, for the even and the odd instructions)
     constexpr int NVAR = (RPI * NW) % 16 == 0 ? 1 : 2;
-    static_assert(!DIRECT || (BN % (RPI * NW) == 0 && (RPI * NW) % 8 == 0), "direct LDS loads");
+    static_assert(!TO_LDS || (BN % (RPI * NW) == 0 && (RPI * NW) % 8 == 0), "direct LDS loads");
     unsigned dk_voff = 0, dv_voff = 0, dk_voff1 = 0, dv_voff1 = 0;
+    // PDIRECT: a wave takes WR consecutive rows of the tile (instruction i the rows RPI * i ...), in
+    // groups of DG rows that share a page and so a descriptor.  The swizzle is linear in the row's
+    // bits and the wave, instruction and lane parts of the row do not overlap, so a lane's chunk in
+    // instruction i is its chunk in instruction 0 XOR a constant.  Chunks in the head-dim padding
+    // are redirected to the last real chunk: they meet zero columns of Q (K) or columns of O that
+    // are never stored (V), and finite data stays finite.
+    constexpr int WR = BN / NW, DG = WR < 16 ? WR : 16, NG = WR / DG, IPG = DG / RPI;
+    static_assert(!PDIRECT || (DG % RPI == 0 && NG <= CH), "paged direct LDS loads");
+    unsigned pcol0 = 0, prow_k = 0, prow_v = 0;
+    const unsigned pcol_max = (unsigned)(p.d / 8 - 1) * 16u;
+    if constexpr (PDIRECT) {
+        pcol0 = (unsigned)(((lane % CPR) ^ swz<DP>(WR * wave + lane / CPR)) << 4);
+        prow_k = (unsigned)(lane / CPR) * k_rs2;
+        prow_v = (unsigned)(lane / CPR) * v_rs2;
+    }
     if constexpr (DIRECT) {
         const int row0 = RPI * wave + lane / CPR;
         const int ch = (lane % CPR) ^ swz<DP>(row0);
@@ -245,7 +266,14 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     int pg[FAST ? 1 : CH];
     constexpr int RSTEP = NT / CPR;  // rows between a lane's chunks = rows of one load round
     auto load_pages = [&](int n) {
-        if constexpr (PAGED_BUF) {
+        if constexpr (PDIRECT) {
+            if (n < 0) return;
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int rb = n * BN + WR * wave + DG * g;  // first row of the wave's group g
+                pg[g] = bt[(rb < sk ? rb : 0) >> p.page_shift];
+            }
+        } else if constexpr (PAGED_BUF) {
             if (n < 0) return;
 #pragma unroll
             for (int i = 0; i < CH; i++) {
@@ -261,6 +289,36 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 const int grow = n * BN + (tid + i * NT) / CPR;
                 const int safe = grow < sk ? grow : 0;
                 pg[i] = bt[p.page_shift >= 0 ? safe >> p.page_shift : safe / p.page_size];
+            }
+        }
+    };
+    auto load_tile_pdirect = [&](int n, auto BUFC) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(BUFC)::value;
+        if constexpr (PDIRECT) {
+            typedef __attribute__((address_space(3))) void *lds_ptr;
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int rb = n * BN + WR * wave + DG * g;
+                const int inpage = rb & (p.page_size - 1);
+                const int pgi = __builtin_amdgcn_readfirstlane(pg[g]);
+                const int valid = min(sk - rb, DG);  // rows of this group that exist
+                const unsigned kb_ = valid > 0 ? (unsigned)(((int64_t)(valid - 1) * p.k_rs + p.d) * 2) : 0u;
+                const unsigned vb_ = valid > 0 ? (unsigned)(((int64_t)(valid - 1) * p.v_rs + p.d) * 2) : 0u;
+                const auto kr_ = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(kg + (int64_t)pgi * p.k_bs + (int64_t)inpage * p.k_rs), 0, kb_, 0x00020000);
+                const auto vr_ = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(vg + (int64_t)pgi * p.v_bs + (int64_t)inpage * p.v_rs), 0, vb_, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < IPG; j++) {
+                    const int i = g * IPG + j;
+                    const unsigned col = min(pcol0 ^ (unsigned)(swz<DP>(RPI * i) << 4), pcol_max);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        kr_, (lds_ptr)(smem + BUF * Cfg::TILE_BYTES + (wave * NI + i) * 1024), 16,
+                        col + prow_k + (unsigned)(RPI * j) * k_rs2, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        vr_, (lds_ptr)(smem + (2 + BUF) * Cfg::TILE_BYTES + (wave * NI + i) * 1024), 16,
+                        col + prow_v + (unsigned)(RPI * j) * v_rs2, 0, 0, 0);
+                }
             }
         }
     };
@@ -385,6 +443,11 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     if constexpr (DIRECT) {
         load_tile_direct(n_max - 1, std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the tile is in LDS
+    } else if constexpr (PDIRECT) {
+        load_pages(n_max - 1);
+        load_tile_pdirect(n_max - 1, std::integral_constant<int, 0>{});
+        if (n_max - 2 >= n_min) load_pages(n_max - 2);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     } else {
         load_pages(n_max - 1);
         load_tile(n_max - 1);
@@ -406,6 +469,9 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         if (has_next) {
             if constexpr (DIRECT) {
                 load_tile_direct(n - 1, std::integral_constant<int, BUF ^ 1>{});
+            } else if constexpr (PDIRECT) {
+                load_tile_pdirect(n - 1, std::integral_constant<int, BUF ^ 1>{});
+                if (n - 2 >= n_min) load_pages(n - 2);
             } else {
                 load_tile(n - 1);
                 if (n - 2 >= n_min) load_pages(n - 2);
@@ -625,7 +691,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         STAMP(3);
         }  // !skip
 
-        if constexpr (DIRECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier
+        if constexpr (TO_LDS) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier
         else if (has_next) store_tile(std::integral_constant<int, BUF ^ 1>{});
         STAMP(4);
         __syncthreads();
@@ -731,6 +797,14 @@ static bool paged_fits_buffer(const KParams &p) {
            (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
 }
 
+// ... straight into LDS: one descriptor per wave and group of at most 16 rows.
+template <int DP>
+static bool paged_fits_direct(const KParams &p) {
+    const int64_t lim = (int64_t)1 << 30;
+    return p.block_table && p.page_shift >= 0 && p.page_size % 16 == 0 &&
+           (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
+}
+
 #endif
 #if !defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)
 template <int DP, bool BF16, int NW>
@@ -738,7 +812,13 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     // contiguous K/V: straight into LDS where the lane map allows it (measured on MI355X against
     // register staging: +2..4 % at seqlen 4096, +9 % at 512..2048, d = 64 +4 %)
     if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, 3>(p, stream);
-    if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2>(p, stream);
+    // paged K/V through per-page descriptors: straight into LDS (measured against register staging,
+    // b4 s4096 h16 causal: page 256 d = 64 633 -> 742, d = 128 854 -> 879 TFLOP/s; above d = 128 the
+    // staging registers do not fit).  Development switch 5 = 1 takes register staging.
+    if (paged_fits_direct<DP>(p) && !(g_tuning[5] == 1 && DP <= 128 && paged_fits_buffer<DP, NW>(p)))
+        return launch_prefill_impl<DP, BF16, NW, 4>(p, stream);
+    if constexpr (DP <= 128)
+        if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2>(p, stream);
     return launch_prefill_impl<DP, BF16, NW, 0>(p, stream);
 }
 
@@ -778,12 +858,12 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
 template <int DP, bool BF16>
 static hipError_t launch_prefill_split(const KParams &p, hipStream_t stream) {
     return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, 3, false, true>(p, stream)
-                             : launch_prefill_impl<DP, BF16, 4, 2, false, true>(p, stream);
+                             : launch_prefill_impl<DP, BF16, 4, 4, false, true>(p, stream);
 }
 // Whether the split variants can load this K/V layout (else the caller takes the decode kernel).
 bool fwd_prefill_split_ok(const KParams &p) {
     if (kv_fits_buffer(p)) return true;
-    return p.d <= 64 ? paged_fits_buffer<64, 4>(p) : (p.d <= 128 ? paged_fits_buffer<128, 4>(p) : paged_fits_buffer<256, 4>(p));
+    return p.d <= 64 ? paged_fits_direct<64>(p) : (p.d <= 128 ? paged_fits_direct<128>(p) : paged_fits_direct<256>(p));
 }
 hipError_t run_fwd_prefill_split(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
