@@ -13,6 +13,10 @@ import bench
 
 
 def main():
+    for a in list(sys.argv[1:]):   # --lib=path: another build of the library
+        if a.startswith("--lib="):
+            cabi.LIB_PATH = os.path.abspath(a.split("=", 1)[1])
+            sys.argv.remove(a)
     hip = bench.Hip()
     lib = cabi.lib()
     torch.manual_seed(0)
@@ -21,8 +25,12 @@ def main():
               (16, 1024, 16, 16, 128, True, "bf16"), (32, 512, 16, 16, 128, True, "bf16"),
               (4, 2048, 16, 16, 64, True, "bf16"), (8, 4096, 32, 32, 64, True, "bf16"),
               (4, 4096, 16, 16, 256, True, "bf16"), (4, 4096, 16, 16, 256, False, "bf16"),
-              (4, 4096, 16, 16, 192, True, "bf16")]
-    variants = [1, 2]   # development switch 0: 1 = 8 waves x 32 keys, 2 = 4 waves x 64 keys, 3 = two-phase 8 waves
+              (4, 4096, 16, 16, 192, True, "bf16"),
+              (32, 512, 16, 16, 128, False, "bf16"), (16, 1024, 16, 16, 128, False, "bf16"),     # 11, 12
+              (8, 2048, 16, 16, 128, True, "bf16"), (8, 2048, 16, 16, 128, False, "bf16"),       # 13, 14
+              (32, 512, 32, 32, 64, True, "bf16"), (16, 1024, 32, 32, 64, True, "bf16"),         # 15, 16
+              (32, 512, 32, 32, 64, False, "bf16"), (8, 2048, 32, 32, 64, True, "bf16")]         # 17, 18
+    variants = [1, 2]   # development switch 0: 1 = 8 waves x 32 keys, 2 = 4 waves x 64 keys, 3 = two-phase 8 waves, 5 = 4 waves x 32 keys
     args = sys.argv[1:]
     zeros = "--zeros" in args   # all-zero inputs: same instruction stream, no data-dependent power
     if zeros:

@@ -47,8 +47,22 @@ __device__ unsigned long long g_stamps_dkdv[512 * 8 * 8];
         acc_[slot] += t_ - last_;                                          \
         last_ = t_;                                                        \
     } while (0)
+// ... and the wall-clock (100 MHz) times at which a workgroup enters the kernel, starts and ends its
+// step loop and leaves (slots 0-3), and inside the prologue: block mapping done (4), first slice
+// requested (5), own loads landed (6): the prologue / loop / epilogue split and the occupancy
+// timeline of a launch.
+__device__ unsigned long long g_blk_dkdv[4096 * 8];
+#define BLK_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (wave == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0) {               \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            if (lane == 0) g_blk_dkdv[blockIdx.x * 8 + (i)] = t_;                                 \
+        }                                                                                         \
+    } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define BLK_STAMP(i) do { } while (0)
 #endif
 
 #ifndef VFA_PP_PRIO
@@ -120,7 +134,11 @@ template <int DP, int NW>
 struct BwdCfg {
     static constexpr int NT = NW * 64;
     static constexpr int KB = NW * 32;                        // keys per workgroup
-    static constexpr bool V_IN_LDS = NW == 8 || DP == 256;
+#ifndef VFA_DKDV4_V_IN_LDS
+#define VFA_DKDV4_V_IN_LDS 0
+#endif
+    static constexpr bool V_IN_LDS = NW == 8 || DP == 256 || (VFA_DKDV4_V_IN_LDS && DP == 128);
+    static constexpr int WG_PER_CU = (NW == 4 && VFA_DKDV4_V_IN_LDS && DP == 128) ? 2 : 1;
     // d = 256: the dK / dV accumulators of 32 keys x 256 columns are 256 registers, the whole
     // accumulation half of the register file; with S, dP and the K fragments beside them the
     // compiler moves tiles between the register files and scratch all through the step (measured:
@@ -155,7 +173,7 @@ struct BwdCfg {
 };
 
 template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false>
-__global__ void __launch_bounds__(NW * 64, 1)
+__global__ void __launch_bounds__(NW * 64, (BwdCfg<DP, NW>::WG_PER_CU))
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
     constexpr int CPR = Cfg::CPR, NT = Cfg::NT, KB = Cfg::KB;
@@ -169,6 +187,17 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    BLK_STAMP(0);
+    // The kernel arguments are read piece by piece along the prologue, each piece a scalar load
+    // with a wait behind it: one word of every 64-byte line is requested here, so that the later
+    // loads find their lines in the scalar cache.
+    int ka_touch = 0;
+    {
+        const int __attribute__((address_space(4))) *ka =
+            (const int __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(KParams) + 63) / 64); i++) ka_touch |= ka[16 * i];
+    }
 
     // block -> (batch, kv head, key block).  Blocks b and b+8 share an XCD (round-robin dispatch):
     // give each XCD whole (batch, kv head) pairs, so the key blocks of a pair run side by side on
@@ -211,6 +240,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const int k0 = n_block * KB;
     if (k0 >= sk) return;
     const int kw0 = k0 + 32 * wave;  // first key of this wave
+    BLK_STAMP(4);
     // dropout: the forward's Philox state; 1 KiB of LDS per wave behind the kernel's own map
     unsigned long long ph_seed = 0, ph_off = 0;
     unsigned *xch = nullptr;
@@ -228,29 +258,70 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     const unsigned short *kg = (const unsigned short *)p.k + bi.k_off(p.k_bs, p.k_rs, bidb) + (int64_t)hk * p.k_hs;
     const unsigned short *vg = (const unsigned short *)p.v + bi.k_off(p.v_bs, p.v_rs, bidb) + (int64_t)hk * p.v_hs;
 
-    // ---- stage K and V into LDS; zero rows past sk ----
-    {
+    // ---- K (and V where it stays in registers): the B-operand fragments of this wave's 32 keys,
+    // lane (r, hh) holds K[kw0 + r][16 s + 8 hh ..], straight from global memory; rows past sk and
+    // the head-dim padding are zeros.  The V tile (V_IN_LDS) is requested here and written to LDS
+    // after the first Q / dO slice has been requested, so that the prologue waits for one memory
+    // round trip, not two.
+    // (FAST: buffer loads whose descriptor ends at the last valid key row -- no predication, so
+    //  all requests go out back to back; a predicated load is a branch, and a copy behind one of
+    //  them made the compiler wait for the memory in the middle of the sequence)
+    i32x4 kf[KS], vf[V_IN_LDS ? 1 : KS];
+    i32x4 vstage[V_IN_LDS ? Cfg::KV_CH : 1];
+    if constexpr (FAST) {
+        const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)kg, 0, (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2), 0x00020000);
+        const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)vg, 0, (unsigned)(((int64_t)(sk - 1) * p.v_rs + p.d) * 2), 0x00020000);
+        const unsigned krow = (unsigned)(kw0 + r) * (unsigned)p.k_rs * 2, vrow = (unsigned)(kw0 + r) * (unsigned)p.v_rs * 2;
 #pragma unroll
-        for (int i = 0; i < Cfg::KV_CH; i++) {
-            const int c = tid + i * NT;
-            const int row = c / CPR, ch = c % CPR;
-            const bool ok = (k0 + row) < sk && ch * 8 < p.d;
-            const i32x4 kk = ok ? *(const i32x4 *)(kg + (int64_t)(k0 + row) * p.k_rs + ch * 8) : i32x4{0, 0, 0, 0};
-            const i32x4 vv = ok ? *(const i32x4 *)(vg + (int64_t)(k0 + row) * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
-            const int off = lds_off<DP>(row, ch);
-            *(i32x4 *)(smem + Cfg::OFF_K + off) = kk;
-            *(i32x4 *)(smem + Cfg::OFF_VT + off) = vv;
+        for (int s = 0; s < KS; s++) {
+            const int col = (2 * s + hh) * 8;
+            const bool ok = col < p.d;
+            kf[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                k_rsrc, ok ? krow + (unsigned)col * 2 : 0x80000000u, 0, 0));
+            if constexpr (!V_IN_LDS)
+                vf[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    v_rsrc, ok ? vrow + (unsigned)col * 2 : 0x80000000u, 0, 0));
+        }
+        if constexpr (V_IN_LDS) {
+#pragma unroll
+            for (int i = 0; i < Cfg::KV_CH; i++) {
+                const int c = tid + i * NT;
+                const int row = c / CPR, ch = c % CPR;
+                vstage[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    v_rsrc, ch * 8 < p.d ? ((unsigned)(k0 + row) * (unsigned)p.v_rs + (unsigned)ch * 8) * 2 : 0x80000000u, 0, 0));
+            }
+        }
+    } else {
+        const bool rok = kw0 + r < sk;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int col = (2 * s + hh) * 8;
+            const bool ok = rok && col < p.d;
+            kf[s] = ok ? *(const i32x4 *)(kg + (int64_t)(kw0 + r) * p.k_rs + col) : i32x4{0, 0, 0, 0};
+            if constexpr (!V_IN_LDS)
+                vf[s] = ok ? *(const i32x4 *)(vg + (int64_t)(kw0 + r) * p.v_rs + col) : i32x4{0, 0, 0, 0};
+        }
+        if constexpr (V_IN_LDS) {
+#pragma unroll
+            for (int i = 0; i < Cfg::KV_CH; i++) {
+                const int c = tid + i * NT;
+                const int row = c / CPR, ch = c % CPR;
+                const bool ok = (k0 + row) < sk && ch * 8 < p.d;
+                vstage[i] = ok ? *(const i32x4 *)(vg + (int64_t)(k0 + row) * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            }
         }
     }
-    __syncthreads();
-    // B-operand fragments of this wave's 32 keys: lane (r, hh) holds K[kw0 + r][16 s + 8 hh ..]
-    i32x4 kf[KS], vf[V_IN_LDS ? 1 : KS];
+    auto store_v_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (V_IN_LDS) {
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-        kf[s] = *(const i32x4 *)(smem + Cfg::OFF_K + lds_off<DP>(32 * wave + r, 2 * s + hh));
-        if constexpr (!V_IN_LDS)
-            vf[s] = *(const i32x4 *)(smem + Cfg::OFF_VT + lds_off<DP>(32 * wave + r, 2 * s + hh));
-    }
+            for (int i = 0; i < Cfg::KV_CH; i++) {
+                const int c = tid + i * NT;
+                *(i32x4 *)(smem + Cfg::OFF_VT + lds_off<DP>(c / CPR, c % CPR)) = vstage[i];
+            }
+        }
+    };
     const char *vt = smem + Cfg::OFF_VT;
 
     f32x16 dk[NDB], dv[NDB];
@@ -287,6 +358,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // buffers, requested three sub-blocks ahead by loads that write LDS directly; every wave waits
     // for its own pieces (counted vmcnt) in front of the barrier that precedes their first read.
     static_assert(FAST && DP == 128 && NW == 8 && !DROP, "two-phase dK/dV schedule: d = 128, 8 waves");
+    store_v_tile();
+    __syncthreads();
     // Ring layout: the four 256-byte row-constant blocks (lse[32], delta[32] as stored in global
     // memory) first, then the four [Q rows | dO rows] buffers -- every offset the reads add to
     // their per-lane address then fits the 16-bit immediate field of the DS instructions.
@@ -803,19 +876,22 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     int cur_h = 0, cur_m = m_max - 1, nxt_h = 0, nxt_m = m_max - 1;
     advance(nxt_h, nxt_m);
     if constexpr (DIRECT) {
-        if (total_steps > 0) load_rowc(cur_h, cur_m);
+        if (total_steps > 0) {
+            load_rowc(cur_h, cur_m);
+            load_slice_direct(cur_h, cur_m, 0);
+        }
     } else {
         if (total_steps > 0) load_slice(cur_h, cur_m);
     }
     if (SPLIT && total_steps > 0) load_chunk(cur_h, cur_m, 0, 0);
-    __syncthreads();  // every wave has its fragments: the freed tile space becomes the Q buffers
+    asm volatile("" ::"s"(ka_touch));
+    BLK_STAMP(5);
+    store_v_tile();
     if constexpr (DIRECT) {
-        if (total_steps > 0) {
-            load_slice_direct(cur_h, cur_m, 0);
-            store_rowc(0);
-        }
+        if (total_steps > 0) store_rowc(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     } else if (total_steps > 0) store_slice(0);
+    BLK_STAMP(6);
     if (SPLIT && total_steps > 0) {
         store_chunk(0, 0, 0);
         load_chunk(cur_h, cur_m, 1, 0);
@@ -827,6 +903,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
+    BLK_STAMP(1);
     int buf = 0;
     for (int step = 0; step < total_steps; step++) {
         const int bidh = hk * p.h_ratio + h_lo + cur_h, q0s = cur_m * BW_QM;
@@ -1018,6 +1095,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         cur_m = nxt_m;
         advance(nxt_h, nxt_m);
     }
+    BLK_STAMP(2);
 #ifdef VFA_STAMP
     if (lane == 0 && blockIdx.x < 512) {
         unsigned long long *dst = g_stamps_dkdv + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -1087,6 +1165,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         __syncthreads();
     }
     }  // !HS
+    BLK_STAMP(3);
 }
 
 // Sum of the head-split partials -> dk, dv (16 bit), slabs added in index order (deterministic).
@@ -1547,7 +1626,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     const bool w64 = w64_ok && (g_tuning[0] == 2 || (g_tuning[0] == 0 && w64_pays));
     if (w64) e = run_bwd_dkdv_w64(p, stream);
     else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
-    else e = p.seqlen_k > 128 ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
+    else e = (p.seqlen_k > 128 && g_tuning[0] != 5) ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     if (e != hipSuccess) return e;
     if (p.hsplit > 1) {
         const int64_t items = p.part_rows * p.h_k * (p.d / 8);
@@ -1600,5 +1679,8 @@ hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *ev)
 #if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU)
 extern "C" int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_dkdv), n * sizeof(unsigned long long));
+}
+extern "C" int vfa_debug_read_blk_dkdv(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_dkdv), n * sizeof(unsigned long long));
 }
 #endif
