@@ -52,17 +52,21 @@ __device__ unsigned long long g_stamps_dkdv[512 * 8 * 8];
 // requested (5), own loads landed (6): the prologue / loop / epilogue split and the occupancy
 // timeline of a launch.
 __device__ unsigned long long g_blk_dkdv[4096 * 8];
-#define BLK_STAMP(i)                                                                              \
+__device__ unsigned long long g_blk_dq[4096 * 8];   // the same for the dQ kernel
+#define BLK_STAMP_TO(arr, i)                                                                      \
     do {                                                                                          \
         if (wave == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0) {               \
             unsigned long long t_;                                                                \
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-            if (lane == 0) g_blk_dkdv[blockIdx.x * 8 + (i)] = t_;                                 \
+            if (lane == 0) arr[blockIdx.x * 8 + (i)] = t_;                                        \
         }                                                                                         \
     } while (0)
+#define BLK_STAMP(i) BLK_STAMP_TO(g_blk_dkdv, i)
+#define DQ_STAMP(i) BLK_STAMP_TO(g_blk_dq, i)
 #else
 #define STAMP(slot) do { } while (0)
 #define BLK_STAMP(i) do { } while (0)
+#define DQ_STAMP(i) do { } while (0)
 #endif
 
 #ifndef VFA_PP_PRIO
@@ -1281,7 +1285,16 @@ struct DqCfg {
     static constexpr int O_ROWB = DP * 2 + 16;
     static constexpr int KV_LDS = 4 * TILE_BYTES;
     static constexpr int O_LDS = NW * 32 * O_ROWB;
-    static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+    // 8 waves, d <= 128: the Q / dO rows of a wave pass through a private LDS image on their way to
+    // its fragments (coalesced 1-KiB requests; the fragment layout itself reads 32 bytes per row
+    // and request, which keeps the address unit busy for about 4 us per workgroup).  Waves 0 and 1
+    // use the second K / V tile buffers, idle until the loop, waves 2.. the space behind the tiles.
+    static constexpr bool STAGE_F = NW == 8 && DP <= 128;
+    static constexpr int FRAG_BYTES = 2 * 32 * DP * 2;       // Q rows, then dO rows, of one wave
+    static constexpr int F_LDS = STAGE_F ? KV_LDS + (NW - 2) * FRAG_BYTES : 0;
+    static constexpr int LDS0 = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+    static constexpr int LDS_BYTES = LDS0 > F_LDS ? LDS0 : F_LDS;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
 };
 
 template <int DP, bool BF16, int NW, bool FAST, bool DROP>
@@ -1296,6 +1309,15 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    DQ_STAMP(0);
+    // one word of every 64-byte line of the kernel arguments, requested up front (see the dK/dV kernel)
+    int ka_touch = 0;
+    {
+        const int __attribute__((address_space(4))) *ka =
+            (const int __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(KParams) + 63) / 64); i++) ka_touch |= ka[16 * i];
+    }
 
     // block -> (batch, head, m_block): whole (batch, kv head) pairs per XCD; within an XCD, groups
     // of G pairs with the m-blocks heaviest first across the group's pairs (as in the forward)
@@ -1335,6 +1357,7 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
     if (m_block * BM >= sq) return;
+    DQ_STAMP(4);
 
     int n_min = !p.is_local ? 0 : max(0, (m_block * BM + sk - sq - p.wl) / DQ_BN);
     int n_max = (sk + DQ_BN - 1) / DQ_BN;
@@ -1428,20 +1451,77 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
             }
         };
 
+        // The first tile is requested before anything else of the prologue, so that the fragment
+        // loads below share its memory round trip.
+        if constexpr (DIRECT) load_tile_direct(n_max - 1, 0);
+        else load_tile(n_max - 1);
+
         // Q^T and dO^T B-operand fragments; LSE and delta of this lane's query row
+        // (FAST: buffer loads bounded at the last query row -- no predication, the requests go out
+        //  back to back)
         i32x4 qf[KS], dof[KS];
         float lse_r = INFINITY, dl_r = 0.f;
         {
             const int row = q0w + r;
             const bool rok = row < sq;
-            const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
-            const unsigned short *dr = dog + (int64_t)(rok ? row : 0) * p.do_rs;
+            if constexpr (DIRECT && Cfg::STAGE_F) {
+                typedef __attribute__((address_space(3))) void *lds_ptr;
+                const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)qg, 0, (unsigned)(((int64_t)(sq - 1) * p.q_rs + p.d) * 2), 0x00020000);
+                const auto do_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)dog, 0, (unsigned)(((int64_t)(sq - 1) * p.do_rs + p.d) * 2), 0x00020000);
+                char *fb = smem + (wave == 0 ? Cfg::TILE_BYTES : wave == 1 ? 3 * Cfg::TILE_BYTES
+                                                               : Cfg::KV_LDS + (wave - 2) * Cfg::FRAG_BYTES);
+                // lane -> (row, chunk) of its slot in a 1-KiB request; the swizzle is linear in the
+                // row's bits, so the chunk of request i is that of request 0 XOR a constant.  Chunks
+                // in the head-dim padding are redirected to the last real one (they meet zero
+                // columns of K and V, and finite data stays finite).
+                const unsigned col0 = (unsigned)(((lane % CPR) ^ swz<DP>(lane / CPR)) << 4);
+                const unsigned col_max = (unsigned)(p.d / 8 - 1) * 16u;
+                const unsigned lrow_q = (unsigned)(lane / CPR) * (unsigned)p.q_rs * 2, lrow_do = (unsigned)(lane / CPR) * (unsigned)p.do_rs * 2;
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                const int col = 16 * s + 8 * hh;
-                const bool ok = rok && col < p.d;
-                qf[s] = ok ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
-                dof[s] = ok ? *(const i32x4 *)(dr + col) : i32x4{0, 0, 0, 0};
+                for (int i = 0; i < 32 / RPI; i++) {
+                    const unsigned col = min(col0 ^ (unsigned)(swz<DP>(RPI * i) << 4), col_max);
+                    const unsigned rws = (unsigned)(q0w + RPI * i);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lds_ptr)(fb + i * 1024), 16,
+                                                             col + lrow_q + rws * (unsigned)p.q_rs * 2, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(do_rsrc, (lds_ptr)(fb + 32 * DP * 2 + i * 1024), 16,
+                                                             col + lrow_do + rws * (unsigned)p.do_rs * 2, 0, 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the wave's own rows (and the first tile) are in LDS
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    qf[s] = *(const i32x4 *)(fb + lds_off<DP>(r, 2 * s + hh));
+                    dof[s] = *(const i32x4 *)(fb + 32 * DP * 2 + lds_off<DP>(r, 2 * s + hh));
+                }
+                // (the images of waves 0 and 1 are the second tile buffers: read out before the
+                //  barrier that precedes the first request into them)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (FAST) {
+                const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)qg, 0, (unsigned)(((int64_t)(sq - 1) * p.q_rs + p.d) * 2), 0x00020000);
+                const auto do_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)dog, 0, (unsigned)(((int64_t)(sq - 1) * p.do_rs + p.d) * 2), 0x00020000);
+                const unsigned qrow = (unsigned)row * (unsigned)p.q_rs * 2, drow = (unsigned)row * (unsigned)p.do_rs * 2;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int col = 16 * s + 8 * hh;
+                    const bool ok = col < p.d;
+                    qf[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        q_rsrc, ok ? qrow + (unsigned)col * 2 : 0x80000000u, 0, 0));
+                    dof[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        do_rsrc, ok ? drow + (unsigned)col * 2 : 0x80000000u, 0, 0));
+                }
+            } else {
+                const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+                const unsigned short *dr = dog + (int64_t)(rok ? row : 0) * p.do_rs;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int col = 16 * s + 8 * hh;
+                    const bool ok = rok && col < p.d;
+                    qf[s] = ok ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
+                    dof[s] = ok ? *(const i32x4 *)(dr + col) : i32x4{0, 0, 0, 0};
+                }
             }
             if (rok) {
                 lse_r = p.lse[((int64_t)bidb * p.h + bidh) * p.seqlen_q + row];
@@ -1468,14 +1548,13 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
         const float c2 = p.scale_log2;
         const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
 
-        if constexpr (DIRECT) {
-            load_tile_direct(n_max - 1, 0);
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        } else {
-            load_tile(n_max - 1);
-            store_tile(0);
-        }
+        asm volatile("" ::"s"(ka_touch));
+        DQ_STAMP(5);
+        if constexpr (DIRECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        else store_tile(0);
+        DQ_STAMP(6);
         __syncthreads();
+        DQ_STAMP(1);
         int buf = 0;
         for (int n = n_max - 1; n >= n_min; n--) {
             const bool has_next = n > n_min;
@@ -1564,6 +1643,7 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     }
 
     // ---- dq = round16(scale * dQ), stored through LDS as whole rows ----
+    DQ_STAMP(2);
     __syncthreads();
     char *ob = smem + wave * 32 * Cfg::O_ROWB;
 #pragma unroll
@@ -1584,6 +1664,7 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
         if (q0w + row < sq && ch * 8 < p.d)
             *(i32x4 *)(dqg + (int64_t)(q0w + row) * p.dq_rs + ch * 8) = w;
     }
+    DQ_STAMP(3);
 }
 
 template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
@@ -1682,5 +1763,8 @@ extern "C" int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
 }
 extern "C" int vfa_debug_read_blk_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_dkdv), n * sizeof(unsigned long long));
+}
+extern "C" int vfa_debug_read_blk_dq(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_dq), n * sizeof(unsigned long long));
 }
 #endif
