@@ -1155,7 +1155,8 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
                 }
                 *(i32x2 *)(ob + r * Cfg::OUT_ROWB + (32 * (db0 + db) + 8 * g4 + 4 * hh) * 2) = w2;
             }
-        __syncthreads();
+        // (the staging rows are the wave's own and a wave's LDS operations execute in order: no
+        //  barrier between these writes, the reads below and the next round's writes)
         unsigned short *dst = which == 0 ? dkg : dvg;
         const int64_t rs = which == 0 ? p.dk_rs : p.dv_rs;
         constexpr int CPRW = CPR / Cfg::DSPLIT;   // chunks of a row that this workgroup holds
@@ -1166,7 +1167,6 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
             const i32x4 w = *(const i32x4 *)(ob + row * Cfg::OUT_ROWB + ch * 16);
             if (kw0 + row < sk && ch * 8 < p.d) *(i32x4 *)(dst + (int64_t)(kw0 + row) * rs + ch * 8) = w;
         }
-        __syncthreads();
     }
     }  // !HS
     BLK_STAMP(3);
@@ -1655,7 +1655,7 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
             w[1] = pack2<BF16>(dq[db][4 * g4 + 2] * p.scale_rp, dq[db][4 * g4 + 3] * p.scale_rp);
             *(i32x2 *)(ob + r * Cfg::O_ROWB + (32 * db + 8 * g4 + 4 * hh) * 2) = w;
         }
-    __syncthreads();
+    // (the wave's own staging rows, LDS operations of a wave in order: no barrier)
 #pragma unroll
     for (int i = 0; i < (32 * CPR) / 64; i++) {
         const int c = lane + 64 * i;
