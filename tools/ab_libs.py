@@ -11,7 +11,9 @@ import cabi
 import bench
 
 SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 4096, 32, 8, 128, True),
-          (16, 1024, 16, 16, 128, True), (4, 2048, 16, 16, 64, True)]
+          (16, 1024, 16, 16, 128, True), (4, 2048, 16, 16, 64, True),
+          (4, 4096, 32, 32, 64, False), (4, 4096, 32, 32, 64, True), (16, 1024, 32, 32, 64, True),   # 5, 6, 7
+          (32, 512, 16, 16, 128, True), (32, 512, 32, 32, 64, False)]                                 # 8, 9
 
 
 def main():

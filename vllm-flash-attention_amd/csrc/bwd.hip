@@ -272,7 +272,30 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     //  them made the compiler wait for the memory in the middle of the sequence)
     i32x4 kf[KS], vf[V_IN_LDS ? 1 : KS];
     i32x4 vstage[V_IN_LDS ? Cfg::KV_CH : 1];
-    if constexpr (FAST) {
+    // Below d = 128 the tiles go through LDS first and the fragments are read from there: the
+    // single round trip measured 7 % slower at d = 64 (1.18 -> 1.27 ms at b4 s4096 h32; the step
+    // loop comes out of the compiler differently), against 3 % faster at d = 128.
+    constexpr bool VIA_LDS = DP < 128;
+    if constexpr (VIA_LDS) {
+#pragma unroll
+        for (int i = 0; i < Cfg::KV_CH; i++) {
+            const int c = tid + i * NT;
+            const int row = c / CPR, ch = c % CPR;
+            const bool ok = (k0 + row) < sk && ch * 8 < p.d;
+            const i32x4 kk = ok ? *(const i32x4 *)(kg + (int64_t)(k0 + row) * p.k_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            const i32x4 vv = ok ? *(const i32x4 *)(vg + (int64_t)(k0 + row) * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            const int off = lds_off<DP>(row, ch);
+            *(i32x4 *)(smem + Cfg::OFF_K + off) = kk;
+            *(i32x4 *)(smem + Cfg::OFF_VT + off) = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            kf[s] = *(const i32x4 *)(smem + Cfg::OFF_K + lds_off<DP>(32 * wave + r, 2 * s + hh));
+            if constexpr (!V_IN_LDS)
+                vf[s] = *(const i32x4 *)(smem + Cfg::OFF_VT + lds_off<DP>(32 * wave + r, 2 * s + hh));
+        }
+    } else if constexpr (FAST) {
         const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)kg, 0, (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2), 0x00020000);
         const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -318,7 +341,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         }
     }
     auto store_v_tile = [&]() __attribute__((always_inline)) {
-        if constexpr (V_IN_LDS) {
+        if constexpr (V_IN_LDS && !VIA_LDS) {
 #pragma unroll
             for (int i = 0; i < Cfg::KV_CH; i++) {
                 const int c = tid + i * NT;
@@ -888,6 +911,7 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
         if (total_steps > 0) load_slice(cur_h, cur_m);
     }
     if (SPLIT && total_steps > 0) load_chunk(cur_h, cur_m, 0, 0);
+    if constexpr (VIA_LDS) __syncthreads();  // every wave has its fragments: the freed tile space becomes the Q buffers
     asm volatile("" ::"s"(ka_touch));
     BLK_STAMP(5);
     store_v_tile();
