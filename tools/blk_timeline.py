@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: when the workgroups of a dK/dV launch enter, start and end their step loop and leave
 (100 MHz wall clock), from the stamped build (python vllm-flash-attention_amd/build.py --stamp):
-blk_timeline.py [causal] [dq] b s h d"""
+blk_timeline.py [causal] [dq|fwd] b s h d"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):
@@ -11,7 +11,7 @@ import cabi
 cabi.LIB_PATH = os.path.join(ROOT, "vllm-flash-attention_amd", "libvfa_hip_stamp.so")
 lib = cabi.lib()
 causal = "causal" in sys.argv[1:]
-which = "dq" if "dq" in sys.argv[1:] else "dkdv"   # which kernel's stamps
+which = "dq" if "dq" in sys.argv[1:] else ("fwd" if "fwd" in sys.argv[1:] else "dkdv")   # which kernel's stamps
 dims = [int(x) for x in sys.argv[1:] if x.isdigit()]
 b, s, h, d = dims if len(dims) == 4 else (32, 512, 16, 128)
 q, k, v, do = (torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16) for _ in range(4))

@@ -63,8 +63,21 @@ __device__ unsigned long long g_stamps[4096 * 8];
         acc_[slot] += t_ - last_;                                          \
         last_ = t_;                                                        \
     } while (0)
+// ... and the wall-clock (100 MHz) times at which a workgroup enters the kernel (0), has its block
+// mapped (4), has requested Q and the first tile (5), has them (6), starts (1) and ends (2) its tile
+// loop and leaves (3).
+__device__ unsigned long long g_blk_fwd[4096 * 8];
+#define FWD_BLK_STAMP(i)                                                                          \
+    do {                                                                                          \
+        if (wave == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                                  \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            if (lane == 0) g_blk_fwd[blockIdx.x * 8 + (i)] = t_;                                  \
+        }                                                                                         \
+    } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define FWD_BLK_STAMP(i) do { } while (0)
 #endif
 
 constexpr int BN = 64;
@@ -127,6 +140,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    FWD_BLK_STAMP(0);
 
     int bidb, bidh, m_block;
     map_block(p, n_mblocks, 32 * ((NW == 8 || DP == 256) ? 1 : 2), bidb, bidh, m_block);
@@ -165,6 +179,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         oacc_g = p.oaccum + acc_row0 * p.d;
     }
     const int q0w = m_block * BM + wave * 32;  // first query row of this wave
+    FWD_BLK_STAMP(4);
 
     if (n_max <= n_min) {
         // No visible key for this row block: O = 0, LSE = +inf (flash_fwd_kernel.h:70-106);
@@ -442,7 +457,9 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
     if constexpr (DIRECT) {
         load_tile_direct(n_max - 1, std::integral_constant<int, 0>{});
+        FWD_BLK_STAMP(5);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the tile is in LDS
+        FWD_BLK_STAMP(6);
     } else if constexpr (PDIRECT) {
         load_pages(n_max - 1);
         load_tile_pdirect(n_max - 1, std::integral_constant<int, 0>{});
@@ -455,6 +472,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         store_tile(std::integral_constant<int, 0>{});
     }
     __syncthreads();
+    FWD_BLK_STAMP(1);
 
 #ifdef VFA_STAMP
     unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
@@ -704,6 +722,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         tile_step(n, std::integral_constant<int, 1>{});
         if (--n < n_min) break;
     }
+    FWD_BLK_STAMP(2);
 
 #ifdef VFA_STAMP
     if (lane == 0 && blockIdx.x < 512) {
@@ -762,6 +781,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         if (q0w + row < sq && ch * 8 < p.d)
             *(i32x4 *)(og + (int64_t)(q0w + row) * p.o_rs + ch * 8) = w;
     }
+    FWD_BLK_STAMP(3);
 }
 
 template <int DP, bool BF16, int NW, int LD, bool DROP = false, bool SPLIT = false>
@@ -889,6 +909,9 @@ hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream) {
 }  // namespace vfa
 
 #if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU)
+extern "C" int vfa_debug_read_blk_fwd(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_fwd), n * sizeof(unsigned long long));
+}
 extern "C" int vfa_debug_read_stamps(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps), n * sizeof(unsigned long long));
 }
