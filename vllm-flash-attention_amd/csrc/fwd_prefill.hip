@@ -93,7 +93,14 @@ struct PrefillCfg {
     static constexpr int O_ROWB = DP * 2 + 16;             // padded O staging row
     static constexpr int KV_LDS = 4 * TILE_BYTES;          // K0 K1 V0 V1
     static constexpr int O_LDS = NW * 32 * O_ROWB;
-    static constexpr int LDS_BYTES = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+    // Prologue of the 8-wave kernel: the 32 Q rows of a wave pass through a private LDS image
+    // (half a tile buffer) on their way to its fragments: waves 0-1 in the second K buffer, 2-3 in
+    // the second V buffer (both idle until the loop), waves 4-7 behind the tile buffers.
+    static constexpr int QIMG_BYTES = 32 * DP * 2;
+    static constexpr int Q_LDS = KV_LDS + (NW > 4 ? (NW - 4) * QIMG_BYTES : 0);
+    static constexpr int LDS0 = KV_LDS > O_LDS ? KV_LDS : O_LDS;
+    static constexpr int LDS_BYTES = LDS0 > Q_LDS ? LDS0 : Q_LDS;
+    static_assert(TILE_BYTES == 2 * QIMG_BYTES, "two Q images per tile buffer");
     static_assert(TILE_CHUNKS % NT == 0, "tile must divide over threads");
 };
 
@@ -405,9 +412,52 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         }
     };
 
+    // 8 waves (one workgroup per CU, nothing overlaps its prologue): the first tile is requested
+    // before anything else and the Q rows share its memory round trip (measured with the workgroup
+    // timeline: prologue 5.45 -> 4.5 us per workgroup at b8 s4096 h32; with two 4-wave workgroups
+    // per CU the old order is level or ahead).
+    constexpr bool QIMG = TO_LDS && NW == 8;
+    auto request_first_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (DIRECT) {
+            load_tile_direct(n_max - 1, std::integral_constant<int, 0>{});
+        } else if constexpr (PDIRECT) {
+            load_pages(n_max - 1);
+            load_tile_pdirect(n_max - 1, std::integral_constant<int, 0>{});
+            if (n_max - 2 >= n_min) load_pages(n_max - 2);
+        }
+    };
+    if constexpr (QIMG) request_first_tile();
+
     // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[q0w + r][16 s + 8 hh ..] ----
+    // Read in that layout from global memory, a request covers 32 bytes of each of 32 rows, which
+    // keeps the address unit busy for microseconds per workgroup; with the direct-to-LDS tile loads
+    // the wave's rows instead go as coalesced 1-KiB requests into a private LDS image (lane ->
+    // (row, chunk) of its slot; the swizzle is linear in the row's bits, so the chunk of request i
+    // is that of request 0 XOR a constant) and the fragments are read from there.
     i32x4 qf[KS];
-    {
+    const bool q_image = QIMG && (int64_t)(p.seqlen_q + 256) * p.q_rs * 2 < ((int64_t)1 << 30);
+    if (q_image) {
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)qg, 0, (unsigned)(((int64_t)(sq - 1) * p.q_rs + p.d) * 2), 0x00020000);
+        char *fb = smem + (wave < 2 ? Cfg::TILE_BYTES + wave * Cfg::QIMG_BYTES
+                           : wave < 4 ? 3 * Cfg::TILE_BYTES + (wave - 2) * Cfg::QIMG_BYTES
+                                      : Cfg::KV_LDS + (wave - 4) * Cfg::QIMG_BYTES);
+        const int c0_ = (lane % CPR) ^ swz<DP>(lane / CPR);
+        const unsigned lrow = (unsigned)(lane / CPR) * (unsigned)p.q_rs * 2;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; i++) {
+            const int ch = c0_ ^ swz<DP>(RPI * i);
+            const unsigned voff = ch * 8 < p.d ? (unsigned)ch * 16 + lrow + (unsigned)(q0w + RPI * i) * (unsigned)p.q_rs * 2
+                                               : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lds_ptr)(fb + i * 1024), 16, voff, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the wave's Q rows and its part of the first tile are in LDS
+#pragma unroll
+        for (int s = 0; s < KS; s++) qf[s] = *(const i32x4 *)(fb + lds_off<DP>(r, 2 * s + hh));
+        // (read out before the barrier that precedes the first request into the second buffers)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
         const int row = q0w + r;
         const bool rok = row < sq;
         const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
@@ -455,16 +505,11 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             v_rd[db][e] = lds_off<DP>(4 * hh + tr_q + 8 * e, 4 * db + 2 * tr_g + (tr_p >> 1)) + 8 * (tr_p & 1);
     constexpr int ROWB = DP * 2;
 
-    if constexpr (DIRECT) {
-        load_tile_direct(n_max - 1, std::integral_constant<int, 0>{});
+    if constexpr (TO_LDS) {
+        if constexpr (!QIMG) request_first_tile();
         FWD_BLK_STAMP(5);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the tile is in LDS
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the first tile is in LDS
         FWD_BLK_STAMP(6);
-    } else if constexpr (PDIRECT) {
-        load_pages(n_max - 1);
-        load_tile_pdirect(n_max - 1, std::integral_constant<int, 0>{});
-        if (n_max - 2 >= n_min) load_pages(n_max - 2);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
     } else {
         load_pages(n_max - 1);
         load_tile(n_max - 1);
