@@ -103,12 +103,16 @@ __global__ void __launch_bounds__(256)
 bwd_preprocess_kernel(const KParams p) {
     // one 16-lane group per query row: delta = sum_d dO * O (fp32)
     const int lane16 = threadIdx.x & 15;
+    // rows in (batch, query, head) order: the 16 rows of a workgroup are 16 heads of one query
+    // position, contiguous in the usual (batch, seqlen, heads, d) layout
     const int64_t row_id = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int64_t total = (int64_t)p.b * p.h * p.seqlen_q;
     if (row_id >= total) return;
-    const int sqi = (int)(row_id % p.seqlen_q);
-    const int bh = (int)(row_id / p.seqlen_q);
-    const int bidb = bh / p.h, bidh = bh % p.h;
+    const int bidh = (int)(row_id % p.h);
+    const int64_t bs = row_id / p.h;
+    const int sqi = (int)(bs % p.seqlen_q);
+    const int bidb = (int)(bs / p.seqlen_q);
+    const int bh = bidb * p.h + bidh;
     const BlockInfo bi(p, bidb);
     float acc = 0.f;
     if (sqi < bi.sq) {
