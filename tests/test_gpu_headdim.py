@@ -238,3 +238,37 @@ def test_varlen_seqused_k(paged, causal):
         fin = np.isfinite(r_)
         assert np.abs(a[fin] - r_[fin]).max() <= 1e-3
     assert torch.equal(res[0], out)  # the extension module's 19-argument entry plumbs seqused_k too
+
+
+EIGHT_WAVE = [
+    # head dims below the padded one at lengths that take the 8-wave kernels, whose prologues pass
+    # the Q (and dO) rows through LDS images and the K fragments through buffer loads: the chunks
+    # of the head-dim padding must read as zeros (Q, K) or be redirected to real ones (dQ kernel)
+    ("bf16", 1, 1152, 1152, 2, 2, 96, False, (-1, -1), False),
+    ("fp16", 1, 1152, 1152, 2, 1, 80, True, (-1, -1), False),
+    ("bf16", 1, 1100, 1300, 2, 2, 72, True, (-1, -1), True),     # ragged last row block and key block
+    ("bf16", 1, 600, 1100, 2, 2, 40, False, (300, 100), False),  # d = 64 kernels
+    ("fp16", 1, 1030, 1030, 1, 1, 128, True, (-1, -1), False),
+]
+
+
+@pytest.mark.parametrize("case", EIGHT_WAVE, ids=[str(c) for c in EIGHT_WAVE])
+def test_padded_head_dim_in_the_eight_wave_kernels(case):
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import TDT, f32, ulp_tol
+    dt, b, sq, sk, h, hk, d, causal, window, alibi = case
+    torch.manual_seed(d + sq)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    do = torch.randn_like(q)
+    slopes = (torch.rand(b, h, device="cuda") * 0.3) if alibi else None
+    kw = dict(causal=causal, window=window, alibi_slopes=slopes)
+    okw = dict(dtype=dt, causal=causal, window=window, alibi_slopes=None if slopes is None else f32(slopes))
+    out, lse = cabi.fwd(q, k, v, **kw)[:2]
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), **okw)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
+    grads = cabi.bwd(do, q, k, v, out, lse, **kw)[:3]
+    ref = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), ro, rl, **okw)[:3]
+    _check_grads(grads, ref, dt)
