@@ -284,6 +284,14 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
             }
         }
     }
+    // The first tile is requested before the query fragments are touched: wave 0's copy of them
+    // into LDS waits for their loads, and the page ids and K/V rows behind that wait would make
+    // the prologue one memory round trip longer (a sequence's first tile is its whole life at
+    // small batch with many splits).
+    load_pages(n_max - 1);
+    load_tile(n_max - 1);
+    if (n_max - 1 > n_min) load_pages(n_max - 2);
+
     char *q_lds = smem + Cfg::KV_LDS;  // fragment s of lane l at (s * 64 + l) * 16
     if constexpr (Cfg::Q_LDS > 0) {
         if (wave_id == 0) {
@@ -312,9 +320,6 @@ fwd_decode_kernel(const KParams p, const int n_mblocks) {
     const int wrow = 32 * wave;      // this wave's rows of the staged tile
     const int hch = hsel * CPR;      // first 16-byte chunk of this wave's head in a staged row
 
-    load_pages(n_max - 1);
-    load_tile(n_max - 1);
-    if (n_max - 1 > n_min) load_pages(n_max - 2);
     for (int n = n_max - 1; n >= n_min; n--) {
         store_tile();
         __syncthreads();
