@@ -281,16 +281,38 @@ bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     // loop comes out of the compiler differently), against 3 % faster at d = 128.
     constexpr bool VIA_LDS = DP < 128;
     if constexpr (VIA_LDS) {
+        i32x4 kk[Cfg::KV_CH], vv[Cfg::KV_CH];
+        if constexpr (FAST) {   // unpredicated: all requests go out before the first result is used
+            const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)kg, 0, (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2), 0x00020000);
+            const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)vg, 0, (unsigned)(((int64_t)(sk - 1) * p.v_rs + p.d) * 2), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < Cfg::KV_CH; i++) {
+                const int c = tid + i * NT;
+                const int row = c / CPR, ch = c % CPR;
+                const bool ok = ch * 8 < p.d;
+                kk[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    k_rsrc, ok ? ((unsigned)(k0 + row) * (unsigned)p.k_rs + (unsigned)ch * 8) * 2 : 0x80000000u, 0, 0));
+                vv[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    v_rsrc, ok ? ((unsigned)(k0 + row) * (unsigned)p.v_rs + (unsigned)ch * 8) * 2 : 0x80000000u, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::KV_CH; i++) {
+                const int c = tid + i * NT;
+                const int row = c / CPR, ch = c % CPR;
+                const bool ok = (k0 + row) < sk && ch * 8 < p.d;
+                kk[i] = ok ? *(const i32x4 *)(kg + (int64_t)(k0 + row) * p.k_rs + ch * 8) : i32x4{0, 0, 0, 0};
+                vv[i] = ok ? *(const i32x4 *)(vg + (int64_t)(k0 + row) * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
+            }
+        }
 #pragma unroll
         for (int i = 0; i < Cfg::KV_CH; i++) {
             const int c = tid + i * NT;
-            const int row = c / CPR, ch = c % CPR;
-            const bool ok = (k0 + row) < sk && ch * 8 < p.d;
-            const i32x4 kk = ok ? *(const i32x4 *)(kg + (int64_t)(k0 + row) * p.k_rs + ch * 8) : i32x4{0, 0, 0, 0};
-            const i32x4 vv = ok ? *(const i32x4 *)(vg + (int64_t)(k0 + row) * p.v_rs + ch * 8) : i32x4{0, 0, 0, 0};
-            const int off = lds_off<DP>(row, ch);
-            *(i32x4 *)(smem + Cfg::OFF_K + off) = kk;
-            *(i32x4 *)(smem + Cfg::OFF_VT + off) = vv;
+            const int off = lds_off<DP>(c / CPR, c % CPR);
+            *(i32x4 *)(smem + Cfg::OFF_K + off) = kk[i];
+            *(i32x4 *)(smem + Cfg::OFF_VT + off) = vv[i];
         }
         __syncthreads();
 #pragma unroll
