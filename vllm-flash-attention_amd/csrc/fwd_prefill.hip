@@ -899,7 +899,8 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     // stalls and split a causal diagonal more finely.  Measured on MI355X (bf16, 16k..64k tokens,
     // seqlen 512..16k): d = 64 is faster with 4 waves everywhere (+8..40 %); d = 128 without a mask
     // is faster with 8 waves everywhere measured (+3..9 %); d = 128 causal / windowed crosses over
-    // between seqlen 2048 (equal) and 4096 (+3 % for 8 waves; +5 % at 16k).
+    // between seqlen 2048 (-1 %) and 3072 (+2 % for 8 waves; +2..3 % at 4096, +5 % at 16k;
+    // tools/ab_fwd_waves.py).
     const bool masked = p.is_causal || p.is_local;
     // Under a window the keys a row block sees are the window's span, not the sequence: 4 waves
     // are faster up to a span of 2048 (b2 s8192 h16, left window 256 / 1024 / 2048: -14 / -7 / -7 %
@@ -907,7 +908,9 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     int64_t span = p.seqlen_k;
     if (p.is_local)
         span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
-    const bool big = masked ? (p.seqlen_q >= 4096 && span >= 3072) : p.seqlen_q >= 512;
+    bool big = masked ? (p.seqlen_q >= 3072 && span >= 3072) : p.seqlen_q >= 512;
+    if (g_tuning[6] == 1) big = true;        // development switch 6: 1 = 8 waves, 2 = 4 waves
+    else if (g_tuning[6] == 2) big = false;
     if (p.d <= 64) {
         return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
     } else if (p.d <= 128) {
