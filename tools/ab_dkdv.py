@@ -39,6 +39,11 @@ def main():
         if a.startswith("--variants="):
             variants = [int(x) for x in a.split("=")[1].split(",")]
             args.remove(a)
+    switch = 0
+    for a in list(args):
+        if a.startswith("--switch="):   # which development switch the variants are values of
+            switch = int(a.split("=")[1])
+            args.remove(a)
     if args:
         shapes = [shapes[int(a)] for a in args]
     stream = torch.cuda.current_stream().cuda_stream
@@ -65,7 +70,7 @@ def main():
         n = 7
         for rnd in range(n + 2):
             for var in variants:
-                lib.vfa_debug_set_tuning(0, var)
+                lib.vfa_debug_set_tuning(switch, var)
                 Pb = res[var][2]
                 ev = (C.c_void_p * 4)(*[hip.event() for _ in range(4)])
                 Pb.stage_events = C.cast(ev, C.c_void_p)
@@ -74,13 +79,14 @@ def main():
                 if rnd >= 2:
                     times[var].append((hip.elapsed_ms(C.c_void_p(ev[1]), C.c_void_p(ev[2])),
                                        hip.elapsed_ms(C.c_void_p(ev[2]), C.c_void_p(ev[3]))))
-        lib.vfa_debug_set_tuning(0, 0)
+        lib.vfa_debug_set_tuning(switch, 0)
         med = lambda xs: sorted(xs)[len(xs) // 2]
         f = bench.fwd_flops(b, s, s, h, d, causal)
         line = f"b{b} s{s} h{h}/{hk} d{d} causal={causal}:"
         for var in variants:
             t = med([x[0] for x in times[var]])
-            line += f"  v{var} dkdv {t:.3f} ms ({2 * f / t / 1e9:.0f} TF exec)"
+            t2 = med([x[1] for x in times[var]])
+            line += f"  v{var} dkdv {t:.3f} ms ({2 * f / t / 1e9:.0f} TF exec) dq {t2:.3f} ms"
         dk1, dv1 = res[variants[0]][0].float(), res[variants[0]][1].float()
         dk2, dv2 = res[variants[-1]][0].float(), res[variants[-1]][1].float()
         ek = (dk1 - dk2).abs().max().item() / max(1.0, dk1.abs().max().item())

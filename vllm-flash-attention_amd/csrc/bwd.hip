@@ -1767,10 +1767,12 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     }
     if (ev && (e = hipEventRecord(ev[2], stream)) != hipSuccess) return e;
     {
-        // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU: measured
-        // on MI355X (16k tokens, seqlen 512..16k): at d = 64, 4 waves win under a causal / window
-        // mask up to seqlen 4096 (by up to 7 %) and without a mask below 2048; at d = 128, 8 waves
-        // are equal or better (1..4 %) from seqlen 512 without a mask and from 1024 with one.
+        // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU, which
+        // overlap each other's prologues: measured on MI355X (development switch 7, interleaved):
+        // at d = 64, 4 waves win under a causal / window mask up to seqlen 4096 (by up to 9 %) and
+        // without a mask below 2048; at d = 128, under a mask 4 waves win up to seqlen 4096 (b8
+        // s4096 h32 causal: 1.49 vs 1.53 ms) and 8 waves from 8192 (0.70 vs 0.73 ms); without a mask
+        // 8 waves win from 2048 (s4096: 2.70 vs 2.78 ms) and the two are level below.
         const bool masked = p.is_causal || p.is_local;
         // Under a window a row block sees the window's span of keys, not the sequence: below 3072
         // keys two 4-wave workgroups per CU win (b2 s8192 h16 d128, left window 256 / 1024 / 2048:
@@ -1778,8 +1780,10 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         int64_t span = p.seqlen_k;
         if (p.is_local)
             span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
-        const bool big = (DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
-                                   : (masked ? p.seqlen_q >= 1024 : p.seqlen_q >= 512)) && span >= 3072;
+        bool big = (DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
+                             : (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048)) && span >= 3072;
+        if (g_tuning[7] == 1) big = true;        // development switch 7: 1 = 8 waves, 2 = 4 waves
+        else if (g_tuning[7] == 2) big = false;
         if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
         else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
