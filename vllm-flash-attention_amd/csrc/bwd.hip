@@ -1781,7 +1781,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         if (p.is_local)
             span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
         bool big = (DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
-                             : (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048)) && span >= 3072;
+                             : (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048)) && (!p.is_local || span >= 3072);
         if (g_tuning[7] == 1) big = true;        // development switch 7: 1 = 8 waves, 2 = 4 waves
         else if (g_tuning[7] == 2) big = false;
         if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
