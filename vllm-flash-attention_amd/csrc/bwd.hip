@@ -142,11 +142,10 @@ template <int DP, int NW>
 struct BwdCfg {
     static constexpr int NT = NW * 64;
     static constexpr int KB = NW * 32;                        // keys per workgroup
-#ifndef VFA_DKDV4_V_IN_LDS
-#define VFA_DKDV4_V_IN_LDS 0
-#endif
-    static constexpr bool V_IN_LDS = NW == 8 || DP == 256 || (VFA_DKDV4_V_IN_LDS && DP == 128);
-    static constexpr int WG_PER_CU = (NW == 4 && VFA_DKDV4_V_IN_LDS && DP == 128) ? 2 : 1;
+    // (4 waves at d = 128: V in LDS keeps the kernel at 256 registers, so that two workgroups share
+    //  a CU and overlap each other's prologues and epilogues -- the variant for short key ranges)
+    static constexpr bool V_IN_LDS = NW == 8 || DP >= 128;
+    static constexpr int WG_PER_CU = (NW == 4 && DP == 128) ? 2 : 1;
     // d = 256: the dK / dV accumulators of 32 keys x 256 columns are 256 registers, the whole
     // accumulation half of the register file; with S, dP and the K fragments beside them the
     // compiler moves tiles between the register files and scratch all through the step (measured:
@@ -1757,7 +1756,14 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     const bool w64 = w64_ok && (g_tuning[0] == 2 || (g_tuning[0] == 0 && w64_pays));
     if (w64) e = run_bwd_dkdv_w64(p, stream);
     else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
-    else e = (p.seqlen_k > 128 && g_tuning[0] != 5) ? launch_dkdv<DP, BF16, 8, DROP>(p, stream) : launch_dkdv<DP, BF16, 4, DROP>(p, stream);
+    else {
+        // 256 keys per 8-wave workgroup (one per CU); at d = 128 up to 1024 keys two 4-wave workgroups
+        // per CU (128 keys each) are ahead: b32 s512 h16 causal 0.153 -> 0.139 ms, full 0.170 ->
+        // 0.158; s1024 -2 %; level at 2048, 1 % behind from there.  Development switch 0 = 5 / 1: always.
+        const bool small = DP == 128 ? p.seqlen_k <= 1024 : p.seqlen_k <= 128;
+        const bool four = g_tuning[0] == 5 || (small && g_tuning[0] != 1);
+        e = four ? launch_dkdv<DP, BF16, 4, DROP>(p, stream) : launch_dkdv<DP, BF16, 8, DROP>(p, stream);
+    }
     if (e != hipSuccess) return e;
     if (p.hsplit > 1) {
         const int64_t items = p.part_rows * p.h_k * (p.d / 8);
