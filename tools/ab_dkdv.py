@@ -29,7 +29,10 @@ def main():
               (32, 512, 16, 16, 128, False, "bf16"), (16, 1024, 16, 16, 128, False, "bf16"),     # 11, 12
               (8, 2048, 16, 16, 128, True, "bf16"), (8, 2048, 16, 16, 128, False, "bf16"),       # 13, 14
               (32, 512, 32, 32, 64, True, "bf16"), (16, 1024, 32, 32, 64, True, "bf16"),         # 15, 16
-              (32, 512, 32, 32, 64, False, "bf16"), (8, 2048, 32, 32, 64, True, "bf16")]         # 17, 18
+              (32, 512, 32, 32, 64, False, "bf16"), (8, 2048, 32, 32, 64, True, "bf16"),         # 17, 18
+              (2, 8192, 32, 32, 64, True, "bf16"), (1, 16384, 32, 32, 64, True, "bf16"),         # 19, 20
+              (4, 4096, 32, 32, 64, False, "bf16"), (8, 2048, 32, 32, 64, False, "bf16"),        # 21, 22
+              (1, 16384, 16, 16, 128, True, "bf16"), (4, 6144, 16, 16, 128, True, "bf16")]       # 23, 24
     variants = [1, 2]   # development switch 0: 1 = 8 waves x 32 keys, 2 = 4 waves x 64 keys, 3 = two-phase 8 waves, 5 = 4 waves x 32 keys
     args = sys.argv[1:]
     zeros = "--zeros" in args   # all-zero inputs: same instruction stream, no data-dependent power

@@ -1775,8 +1775,8 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     {
         // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU, which
         // overlap each other's prologues: measured on MI355X (development switch 7, interleaved):
-        // at d = 64, 4 waves win under a causal / window mask up to seqlen 4096 (by up to 9 %) and
-        // without a mask below 2048; at d = 128, under a mask 4 waves win up to seqlen 4096 (b8
+        // at d = 64, 4 waves win everywhere measured (causal s8192: 0.79 vs 0.86 ms, s16k 1.55 vs
+        // 1.60; full s2048 / s4096: 0.39 vs 0.42, 0.75 vs 0.79); at d = 128, under a mask 4 waves win up to seqlen 4096 (b8
         // s4096 h32 causal: 1.49 vs 1.53 ms) and 8 waves from 8192 (0.70 vs 0.73 ms); without a mask
         // 8 waves win from 2048 (s4096: 2.70 vs 2.78 ms) and the two are level below.
         const bool masked = p.is_causal || p.is_local;
@@ -1786,8 +1786,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         int64_t span = p.seqlen_k;
         if (p.is_local)
             span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
-        bool big = (DP == 64 ? (masked ? p.seqlen_q >= 8192 : p.seqlen_q >= 2048)
-                             : (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048)) && (!p.is_local || span >= 3072);
+        bool big = DP != 64 && (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048) && (!p.is_local || span >= 3072);
         if (g_tuning[7] == 1) big = true;        // development switch 7: 1 = 8 waves, 2 = 4 waves
         else if (g_tuning[7] == 2) big = false;
         if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
