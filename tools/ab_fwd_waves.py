@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""8-wave against 4-wave forward workgroups at d = 128 over sequence lengths (development switch 6),
-interleaved in one process (development tool)."""
+"""8-wave against 4-wave forward workgroups over sequence lengths (development switch 6),
+interleaved in one process (development tool): ab_fwd_waves.py [head dim, default 128]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):
@@ -9,9 +9,10 @@ import torch
 import cabi
 
 lib = cabi.lib()
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 for causal in (True, False):
     for s in (256, 512, 1024, 2048, 3072, 4096):
-        b, h, d = 16384 // s, 16, 128
+        b, h, d = 16384 // s, 2048 // D, D
         q, k, v = (torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16) for _ in range(3))
         times = {1: [], 2: []}
         for rnd in range(12):
