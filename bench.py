@@ -143,10 +143,30 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # Poll all ranks: the first one that fails ends the launch.  The survivors would otherwise sit
+    # in the rendezvous or in a barrier until the process group's time-out.
     rc = 0
-    for pr in procs:
-        code = pr.wait()
-        rc = rc or code
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0:
+                rc = code
+                break
+    if rc != 0:
+        for pr in live:
+            pr.terminate()
+        deadline = time.time() + 10.0
+        for pr in live:
+            try:
+                pr.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
     return rc
 
 
@@ -158,8 +178,10 @@ def dist_setup(backend):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world <= 1:
         return None, rank, world, local_rank
+    import datetime
     import torch.distributed as dist
-    dist.init_process_group(backend)
+    # finite: a rank that never arrives fails the others here instead of hanging them
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("VFA_BENCH_PG_TIMEOUT", "300"))))
     return dist, rank, world, local_rank
 
 
@@ -305,6 +327,9 @@ def parse_args(argv=None):
                     help="weak: every rank runs the per-GPU batch; strong: the global batch is sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sdpa", action="store_true")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1,
+                    help="with --selftest-cpu: this rank exits with status 3 before the rendezvous "
+                         "(checks that the launcher ends the other ranks and reports the failure)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher / sharding / aggregation self-test on CPU ranks (gloo); the step is a stub, "
                          "no attention work is timed and the line says so")
@@ -332,6 +357,8 @@ def selftest_rank(args):
     """One CPU rank of the launcher self-test: the real rendezvous (gloo), sharding, barrier,
     max-over-ranks, work sum and output line of run_rank around a stub step."""
     import numpy as np
+    if int(os.environ.get("RANK", "0")) == args.selftest_fail_rank:
+        sys.exit(3)
     dist, rank, world, _ = dist_setup("gloo")
     dev = torch.device("cpu")
     b = 8

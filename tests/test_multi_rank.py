@@ -95,6 +95,18 @@ def test_bench_gpus_flag_starts_that_many_ranks():
         assert line["value"] > 0
 
 
+def test_launcher_fails_fast_when_a_rank_dies_before_the_rendezvous():
+    """A rank that exits before joining the process group must end the launch at once with its
+    exit status: the other ranks are terminated instead of waiting in the rendezvous for the
+    process group's time-out."""
+    import time
+    for bad in (1, 0):
+        t0 = time.time()
+        r = _run_bench("--gpus", "2", "--selftest-cpu", "--selftest-fail-rank", str(bad), "--steps", "2", "--warmup", "0")
+        assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+        assert time.time() - t0 < 60, "launcher waited for the surviving rank's time-out"
+
+
 def test_bench_gpus_flag_fails_cleanly_without_the_gpus():
     """Asking for more GPUs than the node has is an error, not a silent one-rank run; so is a
     --gpus that contradicts the launcher's WORLD_SIZE."""
