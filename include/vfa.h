@@ -23,6 +23,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with hidden visibility: the entry points declared here are its whole
+ * dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define VFA_FP16 0
 #define VFA_BF16 1
@@ -189,6 +194,9 @@ const char *vfa_last_error(void);
 /* Library version string. */
 const char *vfa_version(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,12 @@
 """ctypes binding of the C ABI (include/vfa.h) used by the GPU parity tests, bench.py and smoke()."""
+import contextlib
 import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(ROOT, "vllm-flash-attention_amd", "libvfa_hip.so")
+# development build: every kernel variant + vfa_debug_set_tuning (never loaded by the product)
+DEV_LIB_PATH = os.path.join(ROOT, "vllm-flash-attention_amd", "libvfa_hip_dev.so")
 
 _i64, _int, _f, _p = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -78,6 +81,37 @@ def lib():
     if _lib is None:
         _lib = load(LIB_PATH)
     return _lib
+
+
+_dev = None
+
+
+def dev_lib():
+    """libvfa_hip_dev.so, loaded once."""
+    global _dev
+    if _dev is None:
+        _dev = load(DEV_LIB_PATH)
+        _dev.vfa_debug_set_tuning.argtypes = [_int, _int]
+        _dev.vfa_debug_set_tuning.restype = None
+    return _dev
+
+
+@contextlib.contextmanager
+def dev(switch=None, value=0):
+    """Inside the block every call of this module goes to the development library, with
+    development switch `switch` set to `value` (the library's other switches stay 0)."""
+    global _lib
+    d = dev_lib()
+    prev = lib()
+    _lib = d
+    if switch is not None:
+        d.vfa_debug_set_tuning(switch, value)
+    try:
+        yield d
+    finally:
+        if switch is not None:
+            d.vfa_debug_set_tuning(switch, 0)
+        _lib = prev
 
 
 class VfaError(RuntimeError):

@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/vfa.h but not exported"
 
 
+def test_product_library_exports_nothing_else():
+    """The shipped library's dynamic symbol table is include/vfa.h: no development hook (the
+    kernel-variant switches live in libvfa_hip_dev.so only) and no internal C++ symbol."""
+    import subprocess
+    import cabi
+    out = subprocess.run(["nm", "-D", "--defined-only", cabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TtWw")
+    assert funcs == _declared_functions(), funcs
+    dev = subprocess.run(["nm", "-D", "--defined-only", cabi.DEV_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "vfa_debug_set_tuning" in dev
+
+
 def test_params_struct_mirror_matches():
     import cabi
     assert cabi.lib().vfa_params_sizeof() == ctypes.sizeof(cabi.VfaParams)

@@ -11,12 +11,8 @@ pytestmark = pytest.mark.gpu
 
 def _with_kernel(fn, value=3):
     import cabi
-    lib = cabi.lib()
-    lib.vfa_debug_set_tuning(0, value)
-    try:
+    with cabi.dev(0, value):   # the schedule exists in the development library only
         return fn()
-    finally:
-        lib.vfa_debug_set_tuning(0, 0)
 
 
 CASES = [

@@ -14,12 +14,8 @@ def _cabi():
 
 
 def _both(fn):
-    lib = _cabi().lib()
-    lib.vfa_debug_set_tuning(2, 2)   # packing off
-    try:
+    with _cabi().dev(2, 2):   # development library, packing off
         plain = fn()
-    finally:
-        lib.vfa_debug_set_tuning(2, 0)
     return plain, fn()
 
 

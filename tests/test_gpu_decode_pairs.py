@@ -14,12 +14,8 @@ def _cabi():
 
 
 def _both(fn):
-    lib = _cabi().lib()
-    lib.vfa_debug_set_tuning(1, 1)
-    try:
+    with _cabi().dev(1, 1):   # development library, one head per workgroup
         single = fn()
-    finally:
-        lib.vfa_debug_set_tuning(1, 0)
     return single, fn()
 
 

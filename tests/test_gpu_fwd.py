@@ -195,7 +195,7 @@ def test_varlen_paged_vs_oracle():
 def test_varlen_paged_prefill_equals_contiguous(d, page, sq, causal, staged):
     """Prefill over a paged cache must give the bits of the same call on contiguous K/V: covers the
     per-page buffer-descriptor loads (power-of-two pages of at least 16 rows; straight into LDS, or
-    with development switch 5 = 1 through registers where a page holds whole load rounds) and the
+    -- development library, switch 5 = 1 -- through registers where a page holds whole load rounds) and the
     per-row path (small or odd pages), head dims below the padded one (whose padding chunks are
     redirected to real ones), ragged lengths that end inside a page, NaN in every cache row past a
     sequence's end and in unused pages, and garbage in unused block-table entries."""
@@ -203,14 +203,17 @@ def test_varlen_paged_prefill_equals_contiguous(d, page, sq, causal, staged):
     import cabi
     if staged and (d > 128 or page % 16 or page & (page - 1)):
         pytest.skip("register staging is an alternative only for d <= 128 and power-of-two pages")
-    cabi.lib().vfa_debug_set_tuning(5, 1 if staged else 0)
-    try:
-        _paged_prefill_equals_contiguous(fa, d, page, sq, causal)
-    finally:
-        cabi.lib().vfa_debug_set_tuning(5, 0)
+    if staged:
+        def run(q, k, v, cq, ck, mq, mk, causal, block_table=None):
+            return cabi.fwd(q, k, v, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=mq, max_seqlen_k=mk,
+                            causal=causal, block_table=block_table)[0]
+        with cabi.dev(5, 1):
+            _paged_prefill_equals_contiguous(run, d, page, sq, causal)
+    else:
+        _paged_prefill_equals_contiguous(fa.flash_attn_varlen_func, d, page, sq, causal)
 
 
-def _paged_prefill_equals_contiguous(fa, d, page, sq, causal):
+def _paged_prefill_equals_contiguous(varlen_func, d, page, sq, causal):
     torch.manual_seed(d + page)
     h, hk = 4, 2
     kl = [sq, sq - page // 2 - 3, 37]
@@ -234,8 +237,8 @@ def _paged_prefill_equals_contiguous(fa, d, page, sq, causal):
         bt[i, (n + page - 1) // page:] = 2 ** 30  # never dereferenced
         off += n
     cq, ck = _cu(ql), _cu(kl)
-    ref = fa.flash_attn_varlen_func(q, k, v, cq, ck, max(ql), max(kl), causal=causal)
-    out = fa.flash_attn_varlen_func(q, kc, vc, cq, ck, max(ql), max(kl), causal=causal, block_table=bt.cuda())
+    ref = varlen_func(q, k, v, cq, ck, max(ql), max(kl), causal=causal)
+    out = varlen_func(q, kc, vc, cq, ck, max(ql), max(kl), causal=causal, block_table=bt.cuda())
     assert not torch.isnan(out).any()
     assert torch.equal(out, ref)
 

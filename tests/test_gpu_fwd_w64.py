@@ -14,12 +14,8 @@ def _cabi():
 
 
 def _with_kernel(fn):
-    lib = _cabi().lib()
-    lib.vfa_debug_set_tuning(4, 1)
-    try:
+    with _cabi().dev(4, 1):   # the kernel exists in the development library only
         return fn()
-    finally:
-        lib.vfa_debug_set_tuning(4, 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -8,6 +8,7 @@ for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROO
 import torch
 import vllm_flash_attn as fa
 import cabi
+cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
 
 sw, va, vb = (int(x) for x in sys.argv[1:4])
 h, hk, d, page = 32, 8, 128, 16

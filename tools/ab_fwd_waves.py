@@ -7,6 +7,7 @@ for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROO
     sys.path.insert(0, p)
 import torch
 import cabi
+cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
 
 lib = cabi.lib()
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 128

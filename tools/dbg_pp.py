@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch, cabi
+cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
 lib = cabi.lib()
 b, sq, sk, h, hk, d = [int(x) for x in (sys.argv[1:7] if len(sys.argv) > 6 else (1, 256, 512, 2, 2, 128))]
 causal = len(sys.argv) > 7 and sys.argv[7] == "causal"

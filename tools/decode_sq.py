@@ -16,6 +16,7 @@ vc = torch.randn_like(kc)
 lens = torch.full((b,), kv, dtype=torch.int32, device="cuda")
 gb = 2.0 * b * kv * hk * d * 2 / 1e9
 import cabi
+cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
 flags = [int(a) for a in sys.argv[1:]] or [0]
 for sq in (1, 2, 4, 8, 16, 32, 64, 128):
     q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.float16)

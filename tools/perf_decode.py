@@ -62,6 +62,7 @@ def prefill_paged(d=128):
     ref = fa.flash_attn_varlen_func(q, k, v, cu, cu, s, s, causal=True)
     print(f"prefill contiguous: {t:.3f} ms  {flops / t / 1e9:.0f} TF", flush=True)
     import cabi
+    cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
     for page in (16, 256):
         nb = b * s // page
         perm = torch.randperm(nb, device="cuda")

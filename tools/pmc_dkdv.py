@@ -7,6 +7,7 @@ for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROO
     sys.path.insert(0, p)
 import torch
 import cabi
+cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
 lib = cabi.lib()
 causal = len(sys.argv) < 2 or sys.argv[1] == "causal"
 q = torch.randn(8, 4096, 32, 128, device="cuda", dtype=torch.bfloat16)

@@ -9,6 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "vllm-flash-attention_amd"), os.path.join(ROO
 import ctypes as C
 import torch
 import cabi
+cabi.LIB_PATH = cabi.DEV_LIB_PATH   # the development build: kernel-variant switches
 import bench
 
 hip = bench.Hip()

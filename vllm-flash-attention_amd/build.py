@@ -2,6 +2,8 @@
 """In-tree build of the MI355X FlashAttention library.
 
   libvfa_hip.so                 HIP kernels + C ABI (include/vfa.h), built with hipcc for gfx950
+  libvfa_hip_dev.so             development build (-DVFA_DEV): + kernels no shipped dispatch takes and the
+                                kernel-variant switches; loaded by A/B tools and cross-check tests only
   vllm_flash_attn_2_cuda*.so    PyTorch extension module with the reference's pybind names
                                 (fwd / varlen_fwd / fwd_kvcache / bwd / varlen_bwd); a thin shim
                                 over the C ABI, built with g++ against the torch headers
@@ -23,7 +25,12 @@ OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
-               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip", "fwd_prefill_w64.hip"]
+               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip"]
+# The development library (libvfa_hip_dev.so, -DVFA_DEV) adds the kernels no shipped dispatch takes
+# and the kernel-variant switches (vfa_debug_set_tuning) that select them; the A/B tools and the
+# tests that check a shipped kernel against its alternative load it.  The product never does.
+DEV_SOURCES = HIP_SOURCES + ["fwd_prefill_w64.hip"]
+DEV_LIB = os.path.join(HERE, "libvfa_hip_dev.so")
 # Kernels built for one wave per SIMD (up to 512 registers): MFMA results that vector instructions
 # consume must be allocated in the arch VGPRs, not forced into the accumulator half of the file.
 EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
@@ -32,7 +39,7 @@ EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"],
               "fwd_prefill_split.hip": ["fwd_prefill.hip"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-I", INCLUDE, "-I", CSRC]
 
 
 def _newer(target, deps):
@@ -47,25 +54,34 @@ def _headers():
         os.path.join(INCLUDE, "vfa.h")]
 
 
-def build_hip(force=False):
-    os.makedirs(OBJ, exist_ok=True)
-    hdrs = _headers()
+def _build_lib(lib, sources, objdir, defines, force):
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = _headers() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
     jobs = []
-    for src in HIP_SOURCES:
+    for src in sources:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + hdrs + [os.path.join(CSRC, e) for e in EXTRA_DEPS.get(src, [])]):
-            jobs.append([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) + ["-c", s, "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
                 if r.returncode != 0:
                     sys.stderr.write(r.stdout + r.stderr)
                     raise RuntimeError("hipcc failed: " + " ".join(r.args))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in HIP_SOURCES]
-    if force or jobs or _newer(LIB, objs):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in sources]
+    if force or jobs or _newer(lib, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+def build_hip(force=False):
+    return _build_lib(LIB, HIP_SOURCES, OBJ, [], force)
+
+
+def build_dev(force=False):
+    """libvfa_hip_dev.so: every kernel and the development switches (see DEV_SOURCES)."""
+    return _build_lib(DEV_LIB, DEV_SOURCES, os.path.join(OBJ, "dev"), ["-DVFA_DEV"], force)
 
 
 def build_stamp():
@@ -74,10 +90,10 @@ def build_stamp():
     od = os.path.join(OBJ, "stamp")
     os.makedirs(od, exist_ok=True)
     objs = []
-    for src in HIP_SOURCES:
+    for src in DEV_SOURCES:
         o = os.path.join(od, src.replace(".hip", ".o"))
         subprocess.check_call([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) +
-                              ["-DVFA_STAMP", "-c", os.path.join(CSRC, src), "-o", o])
+                              ["-DVFA_STAMP", "-DVFA_DEV", "-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
@@ -85,18 +101,18 @@ def build_stamp():
 
 def build_variant(name, defines, sources):
     """Development builds for A/B timing: build/libvfa_<name>.so with `defines` (-D...) applied to
-    `sources`, every other object taken from the main build (never loaded by the product)."""
-    build_hip()
+    `sources`, every other object taken from the development build (never loaded by the product)."""
+    build_dev()
     od = os.path.join(OBJ, "variant_" + name)
     os.makedirs(od, exist_ok=True)
     objs = []
-    for src in HIP_SOURCES:
+    for src in DEV_SOURCES:
         if src in sources:
             o = os.path.join(od, src.replace(".hip", ".o"))
-            subprocess.check_call([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) +
+            subprocess.check_call([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + ["-DVFA_DEV"] + list(defines) +
                                   ["-c", os.path.join(CSRC, src), "-o", o])
         else:
-            o = os.path.join(OBJ, src.replace(".hip", ".o"))
+            o = os.path.join(OBJ, "dev", src.replace(".hip", ".o"))
         objs.append(o)
     out = os.path.join(OBJ, "libvfa_%s.so" % name)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
@@ -140,6 +156,7 @@ def build_torch_ext(force=False):
 def build_all(force=False, torch_ext=True):
     lib = build_hip(force)
     ext = build_torch_ext(force) if torch_ext else None
+    build_dev(force)
     return lib, ext
 
 

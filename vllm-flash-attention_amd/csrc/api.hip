@@ -27,11 +27,14 @@ hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *sta
 
 using vfa::KParams;
 
+#ifdef VFA_DEV
+// Development build only (not part of include/vfa.h, absent from libvfa_hip.so): kernel-variant
+// switches for A/B timing and for the tests that check a shipped kernel against its alternative.
 namespace vfa { int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
-// Development hook (not part of include/vfa.h): kernel-variant switches for A/B timing.
-extern "C" void vfa_debug_set_tuning(int idx, int value) {
+extern "C" __attribute__((visibility("default"))) void vfa_debug_set_tuning(int idx, int value) {
     if (idx >= 0 && idx < 8) vfa::g_tuning[idx] = value;
 }
+#endif
 
 static thread_local std::string g_err;
 

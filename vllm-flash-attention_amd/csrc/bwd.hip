@@ -1292,6 +1292,7 @@ static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
 
 template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
 static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
+#ifdef VFA_DEV   // development build only: measured level with the default schedule
     if constexpr (FAST && DP == 128 && NW == 8 && !DROP) {
         // the two-phase schedule (PP in bwd_dkdv_kernel); development switch 0: 3 = always, 4 = never
         // Opt-in: measured level with the default schedule (2.12 vs 2.12 ms on b8 s4096 h32 d128
@@ -1306,6 +1307,7 @@ static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
             return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true, true>(p, stream)
                                 : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false, true>(p, stream);
     }
+#endif
     return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true>(p, stream)
                         : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false>(p, stream);
 }
@@ -1817,13 +1819,13 @@ hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *ev)
 }  // namespace vfa
 
 #if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU)
-extern "C" int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
+extern "C" __attribute__((visibility("default"))) int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_dkdv), n * sizeof(unsigned long long));
 }
-extern "C" int vfa_debug_read_blk_dkdv(unsigned long long *host, size_t n) {
+extern "C" __attribute__((visibility("default"))) int vfa_debug_read_blk_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_dkdv), n * sizeof(unsigned long long));
 }
-extern "C" int vfa_debug_read_blk_dq(unsigned long long *host, size_t n) {
+extern "C" __attribute__((visibility("default"))) int vfa_debug_read_blk_dq(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_dq), n * sizeof(unsigned long long));
 }
 #endif

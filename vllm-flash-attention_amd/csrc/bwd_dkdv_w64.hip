@@ -538,7 +538,7 @@ hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream) {
 }  // namespace vfa
 
 #ifdef VFA_STAMP
-extern "C" int vfa_debug_read_stamps_w64(unsigned long long *host, size_t n) {
+extern "C" __attribute__((visibility("default"))) int vfa_debug_read_stamps_w64(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_w64), n * sizeof(unsigned long long));
 }
 #endif

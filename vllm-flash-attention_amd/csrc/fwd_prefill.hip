@@ -882,8 +882,10 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     // staging registers do not fit).  Development switch 5 = 1 takes register staging.
     if (paged_fits_direct<DP>(p) && !(g_tuning[5] == 1 && DP <= 128 && paged_fits_buffer<DP, NW>(p)))
         return launch_prefill_impl<DP, BF16, NW, 4>(p, stream);
+#ifdef VFA_DEV   // register staging of paged tiles: reachable only through development switch 5
     if constexpr (DP <= 128)
         if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2>(p, stream);
+#endif
     return launch_prefill_impl<DP, BF16, NW, 0>(p, stream);
 }
 
@@ -893,7 +895,9 @@ hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
+#ifdef VFA_DEV   // the 64-rows-per-wave kernel: development build only (measured 3-8 % behind)
     if (g_tuning[4] == 1 && fwd_prefill_w64_ok(p)) return run_fwd_prefill_w64(p, stream);
+#endif
     // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) against two
     // independent 4-wave blocks per CU, which overlap each other's prologue / epilogue / barrier
     // stalls and split a causal diagonal more finely.  Measured on MI355X (bf16, 16k..64k tokens,
@@ -957,10 +961,10 @@ hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream) {
 }  // namespace vfa
 
 #if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU)
-extern "C" int vfa_debug_read_blk_fwd(unsigned long long *host, size_t n) {
+extern "C" __attribute__((visibility("default"))) int vfa_debug_read_blk_fwd(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_blk_fwd), n * sizeof(unsigned long long));
 }
-extern "C" int vfa_debug_read_stamps(unsigned long long *host, size_t n) {
+extern "C" __attribute__((visibility("default"))) int vfa_debug_read_stamps(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps), n * sizeof(unsigned long long));
 }
 #endif

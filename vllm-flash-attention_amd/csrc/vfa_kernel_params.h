@@ -9,14 +9,23 @@
 
 namespace vfa {
 
-// Development switches (kernel-variant selection for A/B timing inside one process), set through
-// vfa_debug_set_tuning(); all zero = the shipped choices.
+// Development switches (kernel-variant selection for A/B timing inside one process).  They exist
+// only in the development build of the library (-DVFA_DEV: libvfa_hip_dev.so, which also holds the
+// kernels no shipped dispatch takes), where vfa_debug_set_tuning() sets them; in the product build
+// the array is a compile-time constant of zeros, every test of it folds away and no call can change
+// which kernel a dispatch takes.  All zero = the shipped choices.
 //   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one
 //   [1] decode kernel: 0 = auto, 1 = always one head per workgroup
 //   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs, bit 1 turns off
 //       the packing of grouped query heads into the rows of their KV head
 //   [4] forward at 64 < d <= 128: 1 = the 64-rows-per-wave kernel wherever it applies
+//   [5] paged prefill: 1 = per-page descriptors through staging registers instead of straight into LDS
+//   [6] forward at d = 128: 1 = 8 waves, 2 = 4 waves;  [7] the same for the dQ kernel
+#ifdef VFA_DEV
 extern int g_tuning[8];
+#else
+constexpr int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
 // Compute units of the current device (cached per thread and device).
 inline int device_num_cus() {
