@@ -111,4 +111,12 @@ def test_forced_64_key_kernel_masks_and_small_head_dims(case):
                                                causal=causal, window=window,
                                                alibi_slopes=None if slopes is None else _f(slopes))
     _check_vs_oracle(dt, (dq, dk, dv), (rdq, rdk, rdv))
-    assert torch.equal(dk, dk8) and torch.equal(dv, dv8)
+    if d > 64:
+        assert torch.equal(dk, dk8) and torch.equal(dv, dv8)
+    else:
+        # below d = 128 the 8-wave kernel subtracts LSE * log2(e) inside the exponent while this one
+        # starts the S accumulator from -LSE / scale: same value, one more rounding, so a P or dS
+        # can land on the other side of a 16-bit rounding boundary
+        eps = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+        for a, a8 in ((dk, dk8), (dv, dv8)):
+            assert np.abs(_f(a) - _f(a8)).max() <= 2 * eps * max(1.0, np.abs(_f(a8)).max())
