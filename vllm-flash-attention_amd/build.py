@@ -25,7 +25,7 @@ OBJ = os.path.join(HERE, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
-               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip"]
+               "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip", "fwd_prefill_persist.hip"]
 # The development library (libvfa_hip_dev.so, -DVFA_DEV) adds the kernels no shipped dispatch takes
 # and the kernel-variant switches (vfa_debug_set_tuning) that select them; the A/B tools and the
 # tests that check a shipped kernel against its alternative load it.  The product never does.

@@ -893,6 +893,10 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 bool fwd_prefill_w64_ok(const KParams &p);
 hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
+bool fwd_prefill_persist_ok(const KParams &p);               // fwd_prefill_persist.hip
+long long fwd_prefill_persist_items(const KParams &p);
+hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream);
+
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
 #ifdef VFA_DEV   // the 64-rows-per-wave kernel: development build only (measured 3-8 % behind)
@@ -918,6 +922,14 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     if (p.d <= 64) {
         return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
     } else if (p.d <= 128) {
+        // Persistent workgroups (fwd_prefill_persist.hip) wherever every CU gets at least two
+        // 256-row blocks to chain: the seams between a CU's blocks then cost no memory round trip.
+        // Measured on MI355X against the choices below (interleaved, bf16): b8 s4096 h32 causal
+        // 892 -> 961 TFLOP/s, full 1013 -> 1077; b4 s8192 h32/8 causal 1010 -> 1060; b32 s512 h16
+        // causal 477 -> 529; b16 s1024 h16 full 869 -> 960.
+        const bool persist_fits = fwd_prefill_persist_ok(p) && fwd_prefill_persist_items(p) >= 2LL * device_num_cus();
+        if (g_tuning[3] == 2 ? fwd_prefill_persist_ok(p) : (persist_fits && g_tuning[3] != 1))
+            return run_fwd_prefill_persist(p, stream);
         if (big) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
         return bf ? launch_prefill<128, true, 4>(p, stream) : launch_prefill<128, false, 4>(p, stream);
     } else {

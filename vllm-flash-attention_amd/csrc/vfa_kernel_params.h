@@ -18,6 +18,7 @@ namespace vfa {
 //   [1] decode kernel: 0 = auto, 1 = always one head per workgroup
 //   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs, bit 1 turns off
 //       the packing of grouped query heads into the rows of their KV head
+//   [3] persistent forward / dQ workgroups: 1 = never, 2 = wherever the kernels can run
 //   [4] forward at 64 < d <= 128: 1 = the 64-rows-per-wave kernel wherever it applies
 //   [5] paged prefill: 1 = per-page descriptors through staging registers instead of straight into LDS
 //   [6] forward at d = 128: 1 = 8 waves, 2 = 4 waves;  [7] the same for the dQ kernel
@@ -289,12 +290,13 @@ __device__ __forceinline__ unsigned keep_bits_klane(unsigned long long seed, uns
 // order starts the heavy blocks of the next pair only as the light ones of this pair finish, which
 // shows as a tail of up to one heavy block per CU.  G covers about two rounds of the XCD's
 // `slots` resident workgroups, so the co-resident blocks still come from few pairs.
-__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, const int slots, int &bidb,
-                                          int &bidh, int &m_block) {
+// L: position in the launch order (the block id of a one-block-per-workgroup launch; a persistent
+// workgroup walks several positions).
+__device__ __forceinline__ void map_block_at(const KParams &p, const int n_mblocks, const int slots, const int L,
+                                             int &bidb, int &bidh, int &m_block) {
     const int g = p.h_ratio;
     const int W = g * n_mblocks;            // blocks per (batch, kv head) pair
     const int P = p.b * p.h_k;
-    const int L = blockIdx.x;
     const int full = (P / 8) * 8 * W;
     int pair, head, mi;
     if (L < full) {
@@ -319,6 +321,10 @@ __device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks,
     bidb = pair / p.h_k;
     bidh = (pair % p.h_k) * g + head;
     m_block = n_mblocks - 1 - mi;
+}
+__device__ __forceinline__ void map_block(const KParams &p, const int n_mblocks, const int slots, int &bidb,
+                                          int &bidh, int &m_block) {
+    map_block_at(p, n_mblocks, slots, (int)blockIdx.x, bidb, bidh, m_block);
 }
 
 
