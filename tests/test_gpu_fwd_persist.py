@@ -100,3 +100,55 @@ def test_shipped_dispatch_takes_it_for_the_headline_shape_and_strided_inputs():
     with cabi.dev(3, 1):
         o0, l0 = cabi.fwd(q, k, v, causal=True)
     assert torch.equal(o, o0) and _lse_equal(l, l0)
+
+
+# ---- the persistent dQ kernel (bwd_dq_persist.hip), same switch; and the persistent dK/dV kernel,
+# which exists in the development library only (switch 0 = 6: measured behind the block kernel) ----
+
+def _bwd_both(do, q, k, v, out, lse, **kw):
+    import cabi
+    with cabi.dev(3, 2) as lib:
+        lib.vfa_debug_set_tuning(0, 6)
+        try:
+            g1 = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
+        finally:
+            lib.vfa_debug_set_tuning(0, 0)
+    with cabi.dev(3, 1):
+        g0 = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
+    return g1, g0
+
+
+@pytest.mark.parametrize("case", SMALL, ids=[str(c) for c in SMALL])
+def test_persistent_dq_vs_oracle_and_block_kernel(case):
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import TDT
+    dt, b, sq, sk, h, hk, d, causal = case
+    torch.manual_seed(sq + 5 * sk)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    do = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    out, lse = cabi.fwd(q, k, v, causal=causal)
+    (dq, dk, dv), (dq0, dk0, dv0) = _bwd_both(do, q, k, v, out, lse, causal=causal)
+    rdq, rdk, rdv, _ = fa_oracle.attention_bwd(_f(do), _f(q), _f(k), _f(v), _f(out), _f(lse), dtype=dt, causal=causal)
+    eps = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    for nm, a, r in (("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv)):
+        err = np.abs(_f(a) - r).max()
+        assert err <= 4 * eps * max(1.0, np.abs(r).max()), (nm, err)
+    assert torch.equal(dq, dq0) and torch.equal(dk, dk0) and torch.equal(dv, dv0)
+
+
+@pytest.mark.parametrize("case", LARGE, ids=[str(c) for c in LARGE])
+def test_persistent_dq_many_rounds_equals_block_kernel(case):
+    import cabi
+    b, sq, sk, h, hk, causal = case
+    torch.manual_seed(sq + 2 * h)
+    q = torch.randn(b, sq, h, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, 128, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn_like(q)
+    out, lse = cabi.fwd(q, k, v, causal=causal)
+    (dq, dk, dv), (dq0, dk0, dv0) = _bwd_both(do, q, k, v, out, lse, causal=causal)
+    assert not torch.isnan(dq).any()
+    assert torch.equal(dq, dq0) and torch.equal(dk, dk0) and torch.equal(dv, dv0)

@@ -18,8 +18,9 @@ SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 4096,
 
 def main():
     args = sys.argv[1:]
-    tune = [a.split("=", 1) for a in args if a.startswith("--tune")]
-    tune = [(int(a[1].split(":")[0]), int(a[1].split(":")[1])) for a in tune]
+    kv = lambda a: tuple(int(x) for x in a.split("=", 1)[1].split(":"))
+    tune = [kv(a) for a in args if a.startswith("--tune=")]
+    tune_last = [kv(a) for a in args if a.startswith("--tune-last=")]   # the last library only
     args = [a for a in args if not a.startswith("--tune")]
     libs = [a for a in args if a.endswith(".so")]
     idx = [int(a) for a in args if a.isdigit()] or [0, 1]
@@ -32,6 +33,8 @@ def main():
         for k, v in tune:
             h.vfa_debug_set_tuning(k, v)
         handles.append(h)
+    for k, v in tune_last:
+        handles[-1].vfa_debug_set_tuning(k, v)
     stream = torch.cuda.current_stream().cuda_stream
     for si in idx:
         b, s, h, hk, d, causal = SHAPES[si]

@@ -1738,6 +1738,12 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
 }
 
 hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream);  // bwd_dkdv_w64.hip
+bool bwd_dkdv_persist_ok(const KParams &p);                          // bwd_dkdv_persist.hip
+long long bwd_dkdv_persist_items(const KParams &p);
+hipError_t run_bwd_dkdv_persist(const KParams &p, hipStream_t stream);
+bool bwd_dq_persist_ok(const KParams &p);                            // bwd_dq_persist.hip
+long long bwd_dq_persist_items(const KParams &p);
+hipError_t run_bwd_dq_persist(const KParams &p, hipStream_t stream);
 
 template <int DP, bool BF16, bool DROP>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
@@ -1756,7 +1762,17 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     const bool w64_ok = DP <= 128 && !DROP && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
     const bool w64_pays = DP == 128 && !p.is_causal && !p.is_local && p.seqlen_k >= 2048 && p.seqlen_q >= 2048;
     const bool w64 = w64_ok && (g_tuning[0] == 2 || (g_tuning[0] == 0 && w64_pays));
-    if (w64) e = run_bwd_dkdv_w64(p, stream);
+    bool persist = false;
+#ifdef VFA_DEV
+    // Persistent dK/dV workgroups (bwd_dkdv_persist.hip): development build only, switch 0 = 6.
+    // Correct, but 11-18 % behind this kernel at seqlen 4096 and 20 % at 512: wrapped in the walk,
+    // the step loop comes out of the compiler with every LDS read directly in front of its MFMA,
+    // under every scheduling strategy of hipcc 7.2 that does not spill.
+    if constexpr (!DROP && DP == 128) persist = g_tuning[0] == 6 && bwd_dkdv_persist_ok(p);
+    if (persist) e = run_bwd_dkdv_persist(p, stream);
+#endif
+    if (persist) {}
+    else if (w64) e = run_bwd_dkdv_w64(p, stream);
     else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     else {
         // 256 keys per 8-wave workgroup (one per CU); at d = 128 up to 1024 keys two 4-wave workgroups
@@ -1791,7 +1807,15 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         bool big = DP != 64 && (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048) && (!p.is_local || span >= 3072);
         if (g_tuning[7] == 1) big = true;        // development switch 7: 1 = 8 waves, 2 = 4 waves
         else if (g_tuning[7] == 2) big = false;
-        if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
+        // Persistent workgroups (bwd_dq_persist.hip) wherever every CU gets at least two 256-row
+        // blocks to chain.
+        bool persist = false;
+        if constexpr (!DROP && DP == 128) {
+            const bool fits = bwd_dq_persist_ok(p) && bwd_dq_persist_items(p) >= 2LL * device_num_cus();
+            persist = g_tuning[3] == 2 ? bwd_dq_persist_ok(p) : (fits && g_tuning[3] != 1);
+        }
+        if (persist) e = run_bwd_dq_persist(p, stream);
+        else if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
         else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;

@@ -39,7 +39,7 @@ struct PersistCfg {
 };
 
 template <bool BF16>
-__global__ void __launch_bounds__(PersistCfg::NT, 2)
+__global__ void __launch_bounds__(PersistCfg::NT, 1)
 fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_items) {
     using Cfg = PersistCfg;
     constexpr int DP = Cfg::DP, NW = Cfg::NW, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, CPR = Cfg::CPR;
@@ -127,10 +127,15 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
         const unsigned short *qg = (const unsigned short *)p.q + (int64_t)b.bidb * p.q_bs + (int64_t)b.bidh * p.q_hs;
         const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qg, 0, q_bytes, 0x00020000);
         const unsigned row0 = (unsigned)(b.m_block * BM + wave * 32);
+        // (opaque: the eight per-lane offsets below are loop invariants the compiler would otherwise
+        //  keep in registers through the tile loop)
+        int qc = qc0;
+        unsigned ql = q_lrow;
+        asm volatile("" : "+v"(qc), "+v"(ql));
 #pragma unroll
         for (int i = 0; i < 32 / RPI; i++) {
-            const int ch = qc0 ^ swz<DP>(RPI * i);
-            const unsigned voff = ch * 8 < p.d ? (unsigned)ch * 16 + q_lrow + (row0 + RPI * i) * q_rs2 : 0x80000000u;
+            const int ch = qc ^ swz<DP>(RPI * i);
+            const unsigned voff = ch * 8 < p.d ? (unsigned)ch * 16 + ql + (row0 + RPI * i) * q_rs2 : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lds_ptr)(qimg + i * 1024), 16, voff, 0, 0, 0);
         }
     };

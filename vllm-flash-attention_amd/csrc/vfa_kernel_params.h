@@ -14,7 +14,8 @@ namespace vfa {
 // kernels no shipped dispatch takes), where vfa_debug_set_tuning() sets them; in the product build
 // the array is a compile-time constant of zeros, every test of it folds away and no call can change
 // which kernel a dispatch takes.  All zero = the shipped choices.
-//   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one
+//   [0] dK/dV kernel: 0 = auto, 1 = force the 8-wave x 32-key kernel, 2 = force the 4-wave x 64-key one,
+//       3 / 4 = two-phase schedule always / never, 5 = 4-wave x 32-key, 6 = persistent workgroups
 //   [1] decode kernel: 0 = auto, 1 = always one head per workgroup
 //   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs, bit 1 turns off
 //       the packing of grouped query heads into the rows of their KV head
