@@ -113,8 +113,14 @@ def _bwd_both(do, q, k, v, out, lse, **kw):
             g1 = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
         finally:
             lib.vfa_debug_set_tuning(0, 0)
-    with cabi.dev(3, 1):
-        g0 = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
+    # reference: one block per workgroup, and the 8-wave dK/dV geometry (switch 0 = 1), whose
+    # accumulation order over sub-blocks and grouped heads the persistent kernel shares
+    with cabi.dev(3, 1) as lib:
+        lib.vfa_debug_set_tuning(0, 1)
+        try:
+            g0 = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
+        finally:
+            lib.vfa_debug_set_tuning(0, 0)
     return g1, g0
 
 
