@@ -38,6 +38,12 @@ SMALL = [
     ("fp16", 2, 640, 900, 8, 2, 96, True),       # padded head dim, grouped heads, sq < sk
     ("bf16", 1, 64, 1000, 2, 2, 128, True),
     ("bf16", 2, 1, 129, 2, 2, 128, False),
+    # d <= 64: 4 waves, 128-row blocks, two workgroups per CU
+    ("bf16", 2, 512, 512, 4, 4, 64, True),
+    ("fp16", 1, 300, 777, 2, 1, 64, False),
+    ("bf16", 2, 640, 900, 8, 2, 48, True),       # padded head dim
+    ("fp16", 1, 1000, 300, 4, 2, 64, True),      # blocks that see no key
+    ("bf16", 3, 129, 63, 2, 1, 32, False),
 ]
 
 
@@ -87,6 +93,37 @@ def test_persistent_forward_many_rounds_equals_block_kernel(case):
     with cabi.dev(3, 2):
         o2, l2 = cabi.fwd(q, k, v, causal=causal, out=out)
     assert torch.equal(o2, o0) and _lse_equal(l2, l0)
+
+
+LARGE64 = [
+    # b, sq, sk, h, hk, d, causal, waves (0 = the shipped 4-wave geometry, 8 = development switch 6 = 1)
+    (4, 2048, 2048, 16, 16, 64, True, 0),      # 1024 positions over 512 workgroups
+    (4, 2048, 2048, 16, 16, 64, True, 8),
+    (8, 640, 700, 12, 4, 64, False, 0),
+    (3, 1408, 1408, 11, 11, 40, True, 0),      # 33 pairs, 11 blocks each, padded head dim
+    (2, 2048, 64, 16, 16, 64, False, 0),       # one tile per block
+    (2, 1000, 3000, 8, 2, 64, True, 8),
+]
+
+
+@pytest.mark.parametrize("case", LARGE64, ids=[str(c) for c in LARGE64])
+def test_persistent_forward_small_head_dims_equal_block_kernel(case):
+    import cabi
+    b, sq, sk, h, hk, d, causal, waves = case
+    torch.manual_seed(sq + h + d)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    with cabi.dev(3, 2) as lib:
+        lib.vfa_debug_set_tuning(6, 1 if waves == 8 else 0)
+        try:
+            o1, l1 = cabi.fwd(q, k, v, causal=causal, out=torch.full_like(q, float("nan")))
+        finally:
+            lib.vfa_debug_set_tuning(6, 0)
+    with cabi.dev(3, 1):
+        o0, l0 = cabi.fwd(q, k, v, causal=causal)
+    assert not torch.isnan(o1).any()
+    assert torch.equal(o1, o0) and _lse_equal(l1, l0)
 
 
 def test_shipped_dispatch_takes_it_for_the_headline_shape_and_strided_inputs():

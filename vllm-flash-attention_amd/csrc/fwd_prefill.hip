@@ -894,8 +894,8 @@ bool fwd_prefill_w64_ok(const KParams &p);
 hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
 bool fwd_prefill_persist_ok(const KParams &p);               // fwd_prefill_persist.hip
-long long fwd_prefill_persist_items(const KParams &p);
-hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream);
+long long fwd_prefill_persist_items(const KParams &p, int waves_override);
+hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream, int waves_override);
 
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
@@ -919,17 +919,26 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     bool big = masked ? (p.seqlen_q >= 3072 && span >= 3072) : p.seqlen_q >= 512;
     if (g_tuning[6] == 1) big = true;        // development switch 6: 1 = 8 waves, 2 = 4 waves
     else if (g_tuning[6] == 2) big = false;
+    // Persistent workgroups (fwd_prefill_persist.hip) wherever every resident workgroup gets at
+    // least two row blocks to chain: the seams between its blocks then cost no memory round trip.
+    // Measured on MI355X against the choices below (interleaved, bf16, d = 128): b8 s4096 h32 causal
+    // 892 -> 961 TFLOP/s, full 1013 -> 1077; b4 s8192 h32/8 causal 1010 -> 1060; b32 s512 h16 causal
+    // 477 -> 529; b16 s1024 h16 full 869 -> 960.  At d <= 64 the walk does not pay (two 4-wave
+    // workgroups per CU already overlap each other's prologues: b4 s2048 h16 causal 0.063 vs 0.064 ms,
+    // b8 s2048 h32 full 0.382 vs 0.357, b32 s512 h32 causal 0.081 vs 0.078; one 8-wave workgroup per
+    // CU 5-15 % behind): those instantiations exist in the development build only (switch 3 = 2).
+    if (p.d > 64 && p.d <= 128) {
+        const bool persist_fits = fwd_prefill_persist_ok(p) && fwd_prefill_persist_items(p, 0) >= 2LL * device_num_cus();
+        if (g_tuning[3] == 2 ? fwd_prefill_persist_ok(p) : (persist_fits && g_tuning[3] != 1))
+            return run_fwd_prefill_persist(p, stream, 0);
+    }
+#ifdef VFA_DEV
+    if (p.d <= 64 && g_tuning[3] == 2 && fwd_prefill_persist_ok(p))
+        return run_fwd_prefill_persist(p, stream, g_tuning[6] == 1 ? 8 : 0);   // switch 6 = 1: 8 waves
+#endif
     if (p.d <= 64) {
         return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
     } else if (p.d <= 128) {
-        // Persistent workgroups (fwd_prefill_persist.hip) wherever every CU gets at least two
-        // 256-row blocks to chain: the seams between a CU's blocks then cost no memory round trip.
-        // Measured on MI355X against the choices below (interleaved, bf16): b8 s4096 h32 causal
-        // 892 -> 961 TFLOP/s, full 1013 -> 1077; b4 s8192 h32/8 causal 1010 -> 1060; b32 s512 h16
-        // causal 477 -> 529; b16 s1024 h16 full 869 -> 960.
-        const bool persist_fits = fwd_prefill_persist_ok(p) && fwd_prefill_persist_items(p) >= 2LL * device_num_cus();
-        if (g_tuning[3] == 2 ? fwd_prefill_persist_ok(p) : (persist_fits && g_tuning[3] != 1))
-            return run_fwd_prefill_persist(p, stream);
         if (big) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
         return bf ? launch_prefill<128, true, 4>(p, stream) : launch_prefill<128, false, 4>(p, stream);
     } else {

@@ -19,29 +19,34 @@
 // 31 - c of every odd round: under a causal mask the cost falls linearly inside a group, so a
 // forward and a reversed round add up to the same cost for every workgroup.
 //
-// Scope: dense batches (no cu_seqlens / block table / cache indirection), 64 < d <= 128, causal or
-// full attention with key / row tails; everything else stays with fwd_prefill_kernel.
+// Scope: dense batches (no cu_seqlens / block table / cache indirection), d <= 128, causal or full
+// attention with key / row tails; everything else stays with fwd_prefill_kernel.
 #include "vfa_kernel_params.h"
 #include <type_traits>
 
 namespace vfa {
 
+// Geometries: d <= 128 with 8 waves (256-row blocks, one workgroup per CU) and d <= 64 with 4 waves
+// (128-row blocks, two workgroups per CU: at d = 64 the softmax outweighs the MFMAs and two
+// independent workgroups overlap their phases better than one of twice the size).
+template <int DP_, int NW_>
 struct PersistCfg {
-    static constexpr int DP = 128, NW = 8, NT = NW * 64, BM = NW * 32, BN = 64, CPR = DP / 8;
+    static constexpr int DP = DP_, NW = NW_, NT = NW * 64, BM = NW * 32, BN = 64, CPR = DP / 8;
+    static constexpr int WG_PER_CU = NW == 4 ? 2 : 1;
     static constexpr int TILE_BYTES = BN * DP * 2;
     static constexpr int KV_LDS = 4 * TILE_BYTES;               // K0 K1 V0 V1
     static constexpr int QIMG_BYTES = 32 * DP * 2;              // a wave's 32 Q rows
-    static constexpr int OST_BYTES = 32 * 128;                  // a wave's O rows, one 64-column half at a time
+    static constexpr int OST_BYTES = 32 * 128;                  // a wave's O rows, 64 columns at a time
     static constexpr int OFF_Q = KV_LDS;
     static constexpr int OFF_O = OFF_Q + NW * QIMG_BYTES;
     static constexpr int LDS_BYTES = OFF_O + NW * OST_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+    static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS per CU");
 };
 
-template <bool BF16>
-__global__ void __launch_bounds__(PersistCfg::NT, 1)
+template <int DP_, bool BF16, int NW_>
+__global__ void __launch_bounds__(NW_ * 64, (PersistCfg<DP_, NW_>::WG_PER_CU))
 fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_items) {
-    using Cfg = PersistCfg;
+    using Cfg = PersistCfg<DP_, NW_>;
     constexpr int DP = Cfg::DP, NW = Cfg::NW, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, CPR = Cfg::CPR;
     constexpr int KS = DP / 16, NDB = DP / 32;
     constexpr int RPI = 64 / CPR;                 // rows per wave instruction of a direct-to-LDS load
@@ -70,7 +75,7 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
             if (++t >= rounds) return false;
             const int s = t * nwx + ((t & 1) ? nwx - 1 - wg : wg);
             if (s >= n_x) continue;
-            map_block_at(p, n_mblocks, 32, 8 * s + xcd, b.bidb, b.bidh, b.m_block);
+            map_block_at(p, n_mblocks, 32 * Cfg::WG_PER_CU, 8 * s + xcd, b.bidb, b.bidh, b.m_block);
             b.n_max = (sk + BN - 1) / BN;
             if (p.is_causal) b.n_max = min(b.n_max, ((b.m_block + 1) * BM + sk - sq + BN - 1) / BN);
             if (b.n_max > 0) return true;
@@ -198,7 +203,7 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
         // 8-byte writes (lane = row) and the 16-byte reads (8 lanes per row) both spread over all banks
         const int wsw = (r >> 1) & 7;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
+        for (int half = 0; half < DP / 64; half++) {
 #pragma unroll
             for (int d2 = 0; d2 < 2; d2++)
 #pragma unroll
@@ -268,9 +273,10 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
             const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks]);
             s[0] = mma32<BF16>(kf, qf[ks], ks == 0 ? zero : s[0]);
         }
+        constexpr bool SPEC = DP >= 128;   // (measured on the block kernel: +1..2 % at d = 128, -2.5 % at d = 64)
         const float mc_old = (m_run == -INFINITY ? 0.f : m_run) * c2;
         float mx = -INFINITY;
-        if (need) {
+        if (!SPEC || need) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const i32x4 kf = *(const i32x4 *)(kb + k_rd[ks] + 32 * ROWB);
@@ -286,8 +292,9 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
                 s[1] = mma32<BF16>(kf2[ks % 3], qf[ks], ks == 0 ? zero : s[1]);
 #pragma unroll
                 for (int j = ks * 16 / KS; j < (ks + 1) * 16 / KS; j++) mx = fmaxf(mx, s[0][j]);
-                {   // pair ks: k-step ks >> 2, dword ks & 3 of its P fragment
-                    const int st = ks >> 2, w = ks & 3, b8 = 8 * (st & 1);
+#pragma unroll
+                for (int pr = ks * 8 / KS; pr < (ks + 1) * 8 / KS; pr++) {   // pair pr: k-step pr >> 2, dword pr & 3 of its P fragment
+                    const int st = pr >> 2, w = pr & 3, b8 = 8 * (st & 1);
                     const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][b8 + 2 * w], c2, -mc_old));
                     const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][b8 + 2 * w + 1], c2, -mc_old));
                     ps[w] += e0 + e1;
@@ -308,9 +315,15 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     s[kb2][j] = (32 * kb2 + (j & 3) + 8 * (j >> 2) < lim) ? s[kb2][j] : -INFINITY;
-            mx = s[0][0];
+            if constexpr (SPEC) {
+                mx = s[0][0];
 #pragma unroll
-            for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
+                for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
+            }
+        }
+        if constexpr (!SPEC) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) mx = fmaxf(mx, s[0][j]);
         }
         // ---- online softmax (softmax.h:135-166), one query row per lane ----
 #pragma unroll
@@ -331,16 +344,21 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
         }
         m_run = m_new;
         const float mc = m_cur * c2;
-        if (need || upd) {   // the early exponentials were taken on unmasked scores or an old reference
+        if constexpr (SPEC) {
+            if (need || upd) {   // the early exponentials were taken on unmasked scores or an old reference
 #pragma unroll
-            for (int w = 0; w < 4; w++) ps[w] = 0.f;
+                for (int w = 0; w < 4; w++) ps[w] = 0.f;
+                exp_step(0, mc);
+                exp_step(1, mc);
+            }
+        } else {
             exp_step(0, mc);
-            exp_step(1, mc);
         }
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            if (ks < 2) exp_step(ks + 2, mc);   // beside the MFMAs of k-step ks
+            if constexpr (SPEC) { if (ks < 2) exp_step(ks + 2, mc); }   // beside the MFMAs of k-step ks
+            else { if (ks < 3) exp_step(ks + 1, mc); }
 #pragma unroll
             for (int db = 0; db < NDB; db++) {
                 const s16x4 v0 = lds_read_tr16(vb + v_rd[db][0] + 16 * ks * ROWB);
@@ -373,9 +391,9 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
     }
 }
 
-// Whether the persistent kernel can run this problem (the caller decides whether it should).
+// Whether a persistent geometry can run this problem (the caller decides whether it should).
 bool fwd_prefill_persist_ok(const KParams &p) {
-    if (p.d <= 64 || p.d > 128) return false;
+    if (p.d > 128) return false;
     if (p.cu_seqlens_q || p.cu_seqlens_k || p.seqused_k || p.block_table || p.cache_batch_idx || p.knew) return false;
     if (p.alibi_slopes || p.is_local) return false;
     if (p.seqlen_q <= 0 || p.seqlen_k <= 0) return false;
@@ -384,31 +402,44 @@ bool fwd_prefill_persist_ok(const KParams &p) {
     return rq * p.q_rs * 2 < lim && rk * p.k_rs * 2 < lim && rk * p.v_rs * 2 < lim;
 }
 
-// Positions of the launch order: (batch, head, 256-row block).
-long long fwd_prefill_persist_items(const KParams &p) {
-    return (long long)((p.seqlen_q + PersistCfg::BM - 1) / PersistCfg::BM) * p.b * p.h;
+// Rows per block of the geometry taken for this head dim (waves = rows / 32).
+int fwd_prefill_persist_block_rows(const KParams &p, int waves_override) {
+    const int nw = waves_override ? waves_override : (p.d <= 64 ? 4 : 8);
+    return 32 * nw;
 }
 
-hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream) {
-    using Cfg = PersistCfg;
+// Positions of the launch order: (batch, head, row block).
+long long fwd_prefill_persist_items(const KParams &p, int waves_override) {
+    const int bm = fwd_prefill_persist_block_rows(p, waves_override);
+    return (long long)((p.seqlen_q + bm - 1) / bm) * p.b * p.h;
+}
+
+template <int DP, bool BF16, int NW>
+static hipError_t launch_persist(const KParams &p, hipStream_t stream) {
+    using Cfg = PersistCfg<DP, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
-    const long long items = fwd_prefill_persist_items(p);
+    const long long items = (long long)n_mblocks * p.b * p.h;
     if (items <= 0) return hipSuccess;
     if (items > 0x7fffffffLL) return hipErrorInvalidValue;
-    // one workgroup per CU, a multiple of 8 (whole rounds over the XCDs)
-    const int grid = std::max(8, device_num_cus() / 8 * 8);
-    static std::atomic<uint64_t> lds_set[2];
-    hipError_t e;
-    if (p.is_bf16) {
-        auto kern = fwd_prefill_persist_kernel<true>;
-        if ((e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set[0])) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks, (int)items);
-    } else {
-        auto kern = fwd_prefill_persist_kernel<false>;
-        if ((e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set[1])) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks, (int)items);
-    }
+    // as many workgroups as stay resident, a multiple of 8 (whole rounds over the XCDs)
+    const int grid = std::max(8, device_num_cus() / 8 * 8) * Cfg::WG_PER_CU;
+    auto kern = fwd_prefill_persist_kernel<DP, BF16, NW>;
+    static std::atomic<uint64_t> lds_set{0};
+    if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks, (int)items);
     return hipGetLastError();
+}
+
+hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream, int waves_override) {
+    const bool bf = p.is_bf16;
+#ifdef VFA_DEV   // measured level with or behind the block kernel: development build only
+    if (p.d <= 64) {
+        if (waves_override == 8) return bf ? launch_persist<64, true, 8>(p, stream) : launch_persist<64, false, 8>(p, stream);
+        return bf ? launch_persist<64, true, 4>(p, stream) : launch_persist<64, false, 4>(p, stream);
+    }
+#endif
+    if (p.d <= 64) return hipErrorInvalidValue;
+    return bf ? launch_persist<128, true, 8>(p, stream) : launch_persist<128, false, 8>(p, stream);
 }
 
 }  // namespace vfa
