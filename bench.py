@@ -398,6 +398,13 @@ def run_rank(args):
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist, rank, world, local_rank = dist_setup("nccl")  # "nccl" is RCCL on ROCm
     import cabi
+    dev_tune = os.environ.get("VFA_BENCH_DEV_TUNE")   # e.g. "3:1,0:1": profile an alternative kernel choice
+    if dev_tune:
+        # development library + kernel-variant switches (never the headline: the line says so)
+        cabi.LIB_PATH = cabi.DEV_LIB_PATH
+        cabi._lib = cabi.dev_lib()
+        for kv in dev_tune.split(","):
+            cabi._lib.vfa_debug_set_tuning(*(int(x) for x in kv.split(":")))
     cabi.lib()
     hip = Hip()
 
@@ -480,7 +487,8 @@ def run_rank(args):
         if mode == "fwd":
             step = lambda: cabi.call("vfa_mha_fwd", Pf)
             work = f_fwd
-            kern_name = "fwd_prefill_kernel"
+            # (d = 128 with two or more 256-row blocks per CU: the persistent-workgroup kernel)
+            kern_name = "fwd_prefill_persist_kernel" if d > 64 and not dev_tune else "fwd_prefill_kernel"
         else:
             do = torch.randn_like(q)
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -492,7 +500,7 @@ def run_rank(args):
                 cabi.call("vfa_mha_fwd", Pf)
                 cabi.call("vfa_mha_bwd", Pb)
             work = 3.5 * f_fwd
-            kern_name = "bwd_dkdv_kernel+bwd_dq_kernel"
+            kern_name = "bwd_dkdv_kernel+bwd_dq_persist_kernel" if not dev_tune else "bwd_dkdv_kernel+bwd_dq_kernel"
         unit = "TFLOP/s"
         metric = ("attention fwd+bwd TFLOPS, seqlen 4096 headdim 128 bf16 causal" if args.workload == "c3"
                   else f"attention {mode} TFLOPS ({args.workload})")
@@ -534,14 +542,15 @@ def run_rank(args):
             extra["bwd_kernels"] = [
                 {"name": "bwd_dkdv_kernel", "avg_ms": a1, "executed_mfma_tflops": 2.0 * f_fwd / a1 / 1e9,
                  "note": "4 MFMA products: S, dP, dV, dK"},
-                {"name": "bwd_dq_kernel", "avg_ms": a2, "executed_mfma_tflops": 1.5 * f_fwd / a2 / 1e9,
+                {"name": kern_name.split("+")[1], "avg_ms": a2, "executed_mfma_tflops": 1.5 * f_fwd / a2 / 1e9,
                  "note": "3 MFMA products: S, dP (recomputed), dQ"}]
             fe = [(hip.event(), hip.event()) for _ in range(n)]
             for a, bb_ in fe:
                 hip.record(a, stream); cabi.call("vfa_mha_fwd", Pf); hip.record(bb_, stream)
             torch.cuda.synchronize()
             fd = sorted(hip.elapsed_ms(a, bb_) for a, bb_ in fe)
-            extra["fwd_kernel"] = {"name": "fwd_prefill_kernel", "avg_ms": sum(fd) / len(fd),
+            extra["fwd_kernel"] = {"name": "fwd_prefill_kernel" if dev_tune else "fwd_prefill_persist_kernel",
+                                   "avg_ms": sum(fd) / len(fd),
                                    "tflops": f_fwd / (sum(fd) / len(fd)) / 1e9}
         else:
             fe = [(hip.event(), hip.event()) for _ in range(n)]
@@ -588,7 +597,8 @@ def run_rank(args):
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: b{b} sq{sq} sk{sk} h{h}/{hk} d{d} {dtype} causal={causal} {mode}",
                        "per_gpu_batch": len(c4_lens) if mode == "varlen_fwd" else b,
-                       "parallelism": f"batch-sharded replicas x{world}, no collective"},
+                       "parallelism": f"batch-sharded replicas x{world}, no collective",
+                       **({"dev_tuning": dev_tune} if dev_tune else {})},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

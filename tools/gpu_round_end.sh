@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's records come from, on one GPU box: tests, bench lines, kernel-trace
-# stats and the FETCH_SIZE / WRITE_SIZE counter passes.  Each GPU step has its own time limit and
-# the chain stops at the first failure.
+# stats, the FETCH_SIZE / WRITE_SIZE counter passes and the instruction-mix passes.  Each GPU step
+# has its own time limit and the chain stops at the first failure.
 set -e -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/final   # copy what is to be kept into profiles/rNN_*
@@ -14,18 +14,35 @@ for w in c3_fwd c2 c5 c4; do
   timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err
 done
 echo benches done
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -o c3 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sdpa > $O/trace_c3.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5 -o c5 -- python3 bench.py --workload c5 --steps 10 --warmup 3 --no-cpu-baseline --no-sdpa > $O/trace_c5.log 2>&1
+B="--steps 10 --warmup 3 --no-cpu-baseline --no-sdpa"
+for w in c3 c5 c2 c4; do
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -o $w -- python3 bench.py --workload $w $B > $O/trace_$w.log 2>&1
+done
 echo traces done
-for w in c3 c5; do
+S="--steps 3 --warmup 1 --no-cpu-baseline --no-sdpa"
+for w in c3 c5 c2 c4; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$w/$c -o p -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa > $O/pmc_${w}_$c.log 2>&1
+    timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$w/$c -o p -- python3 bench.py --workload $w $S > $O/pmc_${w}_$c.log 2>&1
   done
 done
 # matrix-pipe busy share of the headline kernels (one pass: 2 SQ + 1 GRBM counter)
-timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_c3/MFMA -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa > $O/pmc_c3_MFMA.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_c3/MFMA -o p -- python3 bench.py $S > $O/pmc_c3_MFMA.log 2>&1
+echo traffic done
+python tools/pmc_summarize.py $O/pmc_traffic.json c3=$O/pmc_c3 c5=$O/pmc_c5 c2=$O/pmc_c2 c4=$O/pmc_c4
+# instruction mix of the headline kernels: three passes of <= 8 SQ counters, for the shipped
+# dispatch ("persistent": forward and dQ walk blocks) and for one block per workgroup ("block":
+# development library, switch 3 = 1)
+P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVES"
+P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+P3="SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+i=0
+for P in "$P1" "$P2" "$P3"; do
+  i=$((i+1))
+  timeout -s KILL 200 rocprofv3 --pmc $P --output-format csv -d $O/issue_persistent/p$i -o p -- python3 bench.py $S > $O/issue_persistent_p$i.log 2>&1
+  VFA_BENCH_DEV_TUNE=3:1 timeout -s KILL 200 rocprofv3 --pmc $P --output-format csv -d $O/issue_block/p$i -o p -- python3 bench.py $S > $O/issue_block_p$i.log 2>&1
+done
+python tools/pmc_issue.py $O/pmc_issue.json persistent=$O/issue_persistent block=$O/issue_block
 echo pmc done
-python tools/pmc_summarize.py $O/pmc_traffic.json c3=$O/pmc_c3 c5=$O/pmc_c5
 find $O -name "*kernel_stats.csv" | head
 # keep the merged-back payload small
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete
