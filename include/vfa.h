@@ -184,6 +184,18 @@ size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_
  * (1 = none): see vfa_params.bwd_head_splits. */
 int vfa_bwd_head_splits(int batch, int num_heads, int num_heads_k, int max_seqlen_k, int num_cus);
 
+/* Which kernel geometry a call with these arguments takes (a diagnostic: nothing is launched and
+ * no GPU is needed; the device's CU count is 256 when none is current).  `kernel`: 0 = forward
+ * (vfa_mha_fwd / vfa_mha_varlen_fwd prefill path), 1 = backward dK/dV kernel, 2 = backward dQ
+ * kernel.  Returns a VFA_GEO_* code or a negative vfa_status.  The counterpart of the reference's
+ * tile table and CTA-count test (csrc/flash_attn/src/flash_fwd_launch_template.h:168-370,
+ * csrc/flash_attn/flash_api.cpp:158-219), which the reference does not expose. */
+#define VFA_GEO_BLOCK4 4     /* one 4-wave workgroup per 128-row (128-key) block, two per CU */
+#define VFA_GEO_BLOCK8 8     /* one 8-wave workgroup per 256-row (256-key) block */
+#define VFA_GEO_PERSIST8 18  /* one 8-wave workgroup per CU walks 256-row blocks */
+#define VFA_GEO_WAVE64 64    /* dK/dV: 4 waves x 64 keys, one wave per SIMD */
+int vfa_dispatch_geometry(const vfa_params *p, int kernel);
+
 /* sizeof(vfa_params) of the built library, for foreign-function bindings to check their mirror of
  * the struct against (no counterpart in the reference: its boundary is typed by pybind). */
 size_t vfa_params_sizeof(void);

@@ -71,6 +71,8 @@ def load(path):
     h.vfa_bwd_dq_accum_elems.argtypes = [_int] * 5
     h.vfa_bwd_dq_accum_elems.restype = C.c_size_t
     h.vfa_bwd_head_splits.argtypes = [_int] * 5
+    h.vfa_dispatch_geometry.argtypes = [C.POINTER(VfaParams), _int]
+    h.vfa_dispatch_geometry.restype = _int
     assert h.vfa_params_sizeof() == C.sizeof(VfaParams), "ctypes mirror of vfa_params is stale"
     return h
 

@@ -1,8 +1,9 @@
 """The dK/dV kernel with 64 keys per wave at one wave per SIMD (bwd_dkdv_w64.hip): what the shipped
-dispatch takes for 64 < d <= 128 without a mask once both sequence lengths reach 2048.  Checked
-here ON THE DEFAULT DISPATCH (product library, no switch) against the oracle, and bit for bit
-against the 8-wave kernel (development library, switch 0 = 1); its masked and d <= 64
-instantiations, which only development switch 0 = 2 reaches, go through the same checks."""
+dispatch takes for 64 < d <= 128 without a mask once both sequence lengths reach 3072 and the
+launch has a 256-key block for every CU.  Checked against the oracle and, bit for bit, against the
+8-wave kernel (development library, switch 0 = 1): on the shipped dispatch (product library, no
+switch) for a launch of that size, and forced (switch 0 = 2) on smaller launches and on its masked
+and d <= 64 instantiations."""
 import numpy as np
 import pytest
 import torch
@@ -26,7 +27,8 @@ def _check_vs_oracle(dt, got, ref):
 
 
 DEFAULT_CASES = [
-    # dt, b, sq, sk, h, hk, d, alibi      (no mask, both lengths >= 2048: the default takes the 64-key kernel)
+    # dt, b, sq, sk, h, hk, d, alibi      (no mask, both lengths >= 2048)
+    ("bf16", 8, 3100, 3300, 4, 4, 128, False),     # 416 key blocks: the SHIPPED dispatch takes the 64-key kernel
     ("bf16", 1, 2100, 2300, 2, 2, 128, False),     # row and key tails
     ("fp16", 1, 2048, 2176, 4, 1, 96, False),      # padded head dim, four query heads per KV head
     ("bf16", 1, 2112, 2048, 2, 1, 128, True),      # ALiBi in its |i - j| form
@@ -48,7 +50,11 @@ def test_default_dispatch_long_unmasked_vs_oracle_and_8_wave_kernel(case):
     slopes = (torch.rand(b, h, device="cuda") * 0.3) if alibi else None
     out, lse = cabi.fwd(q, k, v, alibi_slopes=slopes)
     # head_splits = 1: with a split the dispatch keeps the 8-wave kernel
-    dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, alibi_slopes=slopes, head_splits=1)
+    if b * hk * ((sk + 255) // 256) >= 256 and min(sq, sk) >= 3072:   # (tests/test_dispatch.py pins this shape to the 64-key kernel)
+        dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, alibi_slopes=slopes, head_splits=1)
+    else:
+        with cabi.dev(0, 2):
+            dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, alibi_slopes=slopes, head_splits=1)
     rdq, rdk, rdv, _ = fa_oracle.attention_bwd(_f(do), _f(q), _f(k), _f(v), _f(out), _f(lse), dtype=dt,
                                                alibi_slopes=None if slopes is None else _f(slopes))
     _check_vs_oracle(dt, (dq, dk, dv), (rdq, rdk, rdv))
@@ -57,7 +63,7 @@ def test_default_dispatch_long_unmasked_vs_oracle_and_8_wave_kernel(case):
     assert torch.equal(dk, dk8) and torch.equal(dv, dv8) and torch.equal(dq, dq8)
 
 
-def test_default_dispatch_ragged_batch_with_long_and_very_short_sequences():
+def test_ragged_batch_with_long_and_very_short_sequences():
     import cabi
     from oracle import fa_oracle
     torch.manual_seed(11)
@@ -70,7 +76,8 @@ def test_default_dispatch_ragged_batch_with_long_and_very_short_sequences():
     cq, ck = _cu(ql), _cu(kl)
     vk = dict(cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql), max_seqlen_k=max(kl))
     out, lse = cabi.fwd(q, k, v, **vk)
-    dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **vk)
+    with cabi.dev(0, 2):
+        dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **vk)
     nk = dict(cu_seqlens_q=cq.cpu().numpy(), cu_seqlens_k=ck.cpu().numpy(), max_seqlen_q=max(ql), max_seqlen_k=max(kl))
     rdq, rdk, rdv, _ = fa_oracle.attention_bwd(_f(do), _f(q), _f(k), _f(v), _f(out), _f(lse), dtype="bf16", **nk)
     _check_vs_oracle("bf16", (dq, dk, dv), (rdq, rdk, rdv))

@@ -12,6 +12,7 @@
 
 #include "../../include/vfa.h"
 #include "vfa_kernel_params.h"
+#include "vfa_dispatch.h"
 
 namespace vfa {
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream);
@@ -445,6 +446,21 @@ static int bwd_common(const vfa_params *p, bool varlen) {
 
 extern "C" int vfa_mha_bwd(const vfa_params *p) { return bwd_common(p, false); }
 extern "C" int vfa_mha_varlen_bwd(const vfa_params *p) { return bwd_common(p, true); }
+
+extern "C" int vfa_dispatch_geometry(const vfa_params *p, int kernel) {
+    g_err.clear();
+    int rc = common_checks(p);
+    if (rc) return rc;
+    VFA_CHECK(kernel >= 0 && kernel <= 2, "kernel: 0 = forward, 1 = dK/dV, 2 = dQ");
+    KParams k;
+    fill_common(p, k, p->seqlen_q, p->seqlen_k);
+    k.k_cumulative = 1;
+    k.dout = p->dout;
+    k.do_rs = p->do_row_stride;
+    k.hsplit = p->bwd_head_splits > 1 ? p->bwd_head_splits : 0;
+    const int cus = num_cus();
+    return kernel == 0 ? vfa::fwd_geometry(k, cus) : kernel == 1 ? vfa::dkdv_geometry(k, cus) : vfa::dq_geometry(k, cus);
+}
 
 extern "C" size_t vfa_params_sizeof(void) { return sizeof(vfa_params); }
 extern "C" const char *vfa_last_error(void) { return g_err.c_str(); }

@@ -28,6 +28,7 @@
 //                    of 5) and removes the fp32 dQ atomics, which on this chip run at ~1.3 TB/s and
 //                    were the bound of a one-kernel design.
 #include "vfa_kernel_params.h"
+#include "vfa_dispatch.h"
 #include "vfa_one_wave_helpers.h"
 
 namespace vfa {
@@ -1738,6 +1739,12 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
 }
 
 hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream);  // bwd_dkdv_w64.hip
+#ifndef VFA_DROPOUT_TU
+// Whether the 64-keys-per-wave dK/dV kernel can run this problem.
+bool bwd_dkdv_w64_ok(const KParams &p) {
+    return p.d <= 128 && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
+}
+#endif
 bool bwd_dkdv_persist_ok(const KParams &p);                          // bwd_dkdv_persist.hip
 long long bwd_dkdv_persist_items(const KParams &p);
 hipError_t run_bwd_dkdv_persist(const KParams &p, hipStream_t stream);
@@ -1755,33 +1762,22 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (ev && (e = hipEventRecord(ev[1], stream)) != hipSuccess) return e;
-    // 64 keys per wave at one wave per SIMD (bwd_dkdv_w64.hip) where it measured ahead of the 8-wave
-    // kernel: d = 128 on full (unmasked) attention over long key ranges (3-5 % there; level on causal
-    // sweeps, where its waves cannot skip pieces above the diagonal, and behind on short sequences,
-    // where its 256-key blocks leave CUs idle).  Both kernels produce the same bits.
-    const bool w64_ok = DP <= 128 && !DROP && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
-    const bool w64_pays = DP == 128 && !p.is_causal && !p.is_local && p.seqlen_k >= 2048 && p.seqlen_q >= 2048;
-    const bool w64 = w64_ok && (g_tuning[0] == 2 || (g_tuning[0] == 0 && w64_pays));
-    bool persist = false;
+    // the geometry: vfa_dispatch.h (work per CU first, keys per block second).  The 64-keys-per-wave
+    // kernel (bwd_dkdv_w64.hip) and this file's kernels produce the same bits.
+    const int geo_kv = DROP ? (DP == 256 ? VFA_GEO_BLOCK4 : VFA_GEO_BLOCK8) : dkdv_geometry(p, device_num_cus());
+    bool persist_kv = false;
 #ifdef VFA_DEV
     // Persistent dK/dV workgroups (bwd_dkdv_persist.hip): development build only, switch 0 = 6.
     // Correct, but 11-18 % behind this kernel at seqlen 4096 and 20 % at 512: wrapped in the walk,
     // the step loop comes out of the compiler with every LDS read directly in front of its MFMA,
     // under every scheduling strategy of hipcc 7.2 that does not spill.
-    if constexpr (!DROP && DP == 128) persist = g_tuning[0] == 6 && bwd_dkdv_persist_ok(p);
-    if (persist) e = run_bwd_dkdv_persist(p, stream);
+    if constexpr (!DROP && DP == 128) persist_kv = g_tuning[0] == 6 && bwd_dkdv_persist_ok(p);
+    if (persist_kv) e = run_bwd_dkdv_persist(p, stream);
 #endif
-    if (persist) {}
-    else if (w64) e = run_bwd_dkdv_w64(p, stream);
+    if (persist_kv) {}
+    else if (geo_kv == VFA_GEO_WAVE64) e = run_bwd_dkdv_w64(p, stream);
     else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
-    else {
-        // 256 keys per 8-wave workgroup (one per CU); at d = 128 up to 1024 keys two 4-wave workgroups
-        // per CU (128 keys each) are ahead: b32 s512 h16 causal 0.153 -> 0.139 ms, full 0.170 ->
-        // 0.158; s1024 -2 %; level at 2048, 1 % behind from there.  Development switch 0 = 5 / 1: always.
-        const bool small = DP == 128 ? p.seqlen_k <= 1024 : p.seqlen_k <= 128;
-        const bool four = g_tuning[0] == 5 || (small && g_tuning[0] != 1);
-        e = four ? launch_dkdv<DP, BF16, 4, DROP>(p, stream) : launch_dkdv<DP, BF16, 8, DROP>(p, stream);
-    }
+    else e = geo_kv == VFA_GEO_BLOCK4 ? launch_dkdv<DP, BF16, 4, DROP>(p, stream) : launch_dkdv<DP, BF16, 8, DROP>(p, stream);
     if (e != hipSuccess) return e;
     if (p.hsplit > 1) {
         const int64_t items = p.part_rows * p.h_k * (p.d / 8);
@@ -1791,33 +1787,14 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     }
     if (ev && (e = hipEventRecord(ev[2], stream)) != hipSuccess) return e;
     {
-        // 8 waves (256 query rows per workgroup) against two 4-wave workgroups per CU, which
-        // overlap each other's prologues: measured on MI355X (development switch 7, interleaved):
-        // at d = 64, 4 waves win everywhere measured (causal s8192: 0.79 vs 0.86 ms, s16k 1.55 vs
-        // 1.60; full s2048 / s4096: 0.39 vs 0.42, 0.75 vs 0.79); at d = 128, under a mask 4 waves win up to seqlen 4096 (b8
-        // s4096 h32 causal: 1.49 vs 1.53 ms) and 8 waves from 8192 (0.70 vs 0.73 ms); without a mask
-        // 8 waves win from 2048 (s4096: 2.70 vs 2.78 ms) and the two are level below.
-        const bool masked = p.is_causal || p.is_local;
-        // Under a window a row block sees the window's span of keys, not the sequence: below 3072
-        // keys two 4-wave workgroups per CU win (b2 s8192 h16 d128, left window 256 / 1024 / 2048:
-        // backward -7 / -4 / -3 % time), from there 8 waves.
-        int64_t span = p.seqlen_k;
-        if (p.is_local)
-            span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
-        bool big = DP != 64 && (masked ? p.seqlen_q >= 6144 : p.seqlen_q >= 2048) && (!p.is_local || span >= 3072);
-        if (g_tuning[7] == 1) big = true;        // development switch 7: 1 = 8 waves, 2 = 4 waves
-        else if (g_tuning[7] == 2) big = false;
-        // Persistent workgroups (bwd_dq_persist.hip) wherever every CU gets at least two 256-row
-        // blocks to chain.
-        bool persist = false;
-        if constexpr (!DROP && DP == 128) {
-            const bool fits = bwd_dq_persist_ok(p) && bwd_dq_persist_items(p) >= 2LL * device_num_cus();
-            persist = g_tuning[3] == 2 ? bwd_dq_persist_ok(p) : (fits && g_tuning[3] != 1);
-        }
-        if (persist) e = run_bwd_dq_persist(p, stream);
+        // the geometry: vfa_dispatch.h.  Persistent workgroups (bwd_dq_persist.hip) wherever every CU
+        // gets at least two 256-row blocks to chain; else 8 waves (256 query rows per workgroup) or two
+        // 4-wave workgroups per CU, which overlap each other's prologues.
+        const int geo_q = DROP ? VFA_GEO_BLOCK4 : dq_geometry(p, device_num_cus());
+        if (geo_q == VFA_GEO_PERSIST8) e = run_bwd_dq_persist(p, stream);
         else if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
         else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
-        else e = big ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
+        else e = geo_q == VFA_GEO_BLOCK8 ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;
     }
     if (ev && (e = hipEventRecord(ev[3], stream)) != hipSuccess) return e;

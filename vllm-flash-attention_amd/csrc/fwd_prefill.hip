@@ -15,6 +15,7 @@
 //   * masks (causal / sliding window / key tail) and ALiBi are applied in registers, only on
 //     tiles that need them (wave-uniform test).
 #include "vfa_kernel_params.h"
+#include "vfa_dispatch.h"
 #include <type_traits>
 
 namespace vfa {
@@ -893,57 +894,31 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 bool fwd_prefill_w64_ok(const KParams &p);
 hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
-bool fwd_prefill_persist_ok(const KParams &p);               // fwd_prefill_persist.hip
-long long fwd_prefill_persist_items(const KParams &p, int waves_override);
+long long fwd_prefill_persist_items(const KParams &p, int waves_override);   // fwd_prefill_persist.hip
 hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream, int waves_override);
 
 hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
-#ifdef VFA_DEV   // the 64-rows-per-wave kernel: development build only (measured 3-8 % behind)
-    if (g_tuning[4] == 1 && fwd_prefill_w64_ok(p)) return run_fwd_prefill_w64(p, stream);
-#endif
-    // 8 waves x 32 rows (one 256-row block per CU, K/V tiles shared by 8 waves) against two
-    // independent 4-wave blocks per CU, which overlap each other's prologue / epilogue / barrier
-    // stalls and split a causal diagonal more finely.  Measured on MI355X (bf16, 16k..64k tokens,
-    // seqlen 512..16k): d = 64 is faster with 4 waves everywhere (+8..40 %); d = 128 without a mask
-    // is faster with 8 waves everywhere measured (+3..9 %); d = 128 causal / windowed crosses over
-    // between seqlen 2048 (-1 %) and 3072 (+2 % for 8 waves; +2..3 % at 4096, +5 % at 16k;
-    // tools/ab_fwd_waves.py).
-    const bool masked = p.is_causal || p.is_local;
-    // Under a window the keys a row block sees are the window's span, not the sequence: 4 waves
-    // are faster up to a span of 2048 (b2 s8192 h16, left window 256 / 1024 / 2048: -14 / -7 / -7 %
-    // time) and equal from 3072.
-    int64_t span = p.seqlen_k;
-    if (p.is_local)
-        span = std::min<int64_t>(span, (int64_t)(p.wl < 0 ? p.seqlen_k : p.wl) + (p.wr < 0 ? p.seqlen_k : p.wr) + 1);
-    bool big = masked ? (p.seqlen_q >= 3072 && span >= 3072) : p.seqlen_q >= 512;
-    if (g_tuning[6] == 1) big = true;        // development switch 6: 1 = 8 waves, 2 = 4 waves
-    else if (g_tuning[6] == 2) big = false;
-    // Persistent workgroups (fwd_prefill_persist.hip) wherever every resident workgroup gets at
-    // least two row blocks to chain: the seams between its blocks then cost no memory round trip.
-    // Measured on MI355X against the choices below (interleaved, bf16, d = 128): b8 s4096 h32 causal
-    // 892 -> 961 TFLOP/s, full 1013 -> 1077; b4 s8192 h32/8 causal 1010 -> 1060; b32 s512 h16 causal
-    // 477 -> 529; b16 s1024 h16 full 869 -> 960.  At d <= 64 the walk does not pay (two 4-wave
-    // workgroups per CU already overlap each other's prologues: b4 s2048 h16 causal 0.063 vs 0.064 ms,
-    // b8 s2048 h32 full 0.382 vs 0.357, b32 s512 h32 causal 0.081 vs 0.078; one 8-wave workgroup per
-    // CU 5-15 % behind): those instantiations exist in the development build only (switch 3 = 2).
-    if (p.d > 64 && p.d <= 128) {
-        const bool persist_fits = fwd_prefill_persist_ok(p) && fwd_prefill_persist_items(p, 0) >= 2LL * device_num_cus();
-        if (g_tuning[3] == 2 ? fwd_prefill_persist_ok(p) : (persist_fits && g_tuning[3] != 1))
-            return run_fwd_prefill_persist(p, stream, 0);
-    }
 #ifdef VFA_DEV
+    if (g_tuning[4] == 1 && fwd_prefill_w64_ok(p)) return run_fwd_prefill_w64(p, stream);   // 64 rows per wave: 3-8 % behind
+    // persistent workgroups at d <= 64: level with or behind the 4-wave block kernel (two 4-wave
+    // workgroups per CU already overlap each other's prologues: b4 s2048 h16 causal 0.063 vs 0.064 ms,
+    // b8 s2048 h32 full 0.382 vs 0.357; one 8-wave workgroup per CU 5-15 % behind)
     if (p.d <= 64 && g_tuning[3] == 2 && fwd_prefill_persist_ok(p))
-        return run_fwd_prefill_persist(p, stream, g_tuning[6] == 1 ? 8 : 0);   // switch 6 = 1: 8 waves
+        return run_fwd_prefill_persist(p, stream, g_tuning[6] == 1 ? 8 : 0);
 #endif
-    if (p.d <= 64) {
-        return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
-    } else if (p.d <= 128) {
-        if (big) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
-        return bf ? launch_prefill<128, true, 4>(p, stream) : launch_prefill<128, false, 4>(p, stream);
-    } else {
-        return bf ? launch_prefill<256, true, 4>(p, stream) : launch_prefill<256, false, 4>(p, stream);
-    }
+    // the geometry: vfa_dispatch.h (work per CU first, keys per block second)
+    const int geo = fwd_geometry(p, device_num_cus());
+    if (p.d <= 64) return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
+    if (p.d > 128) return bf ? launch_prefill<256, true, 4>(p, stream) : launch_prefill<256, false, 4>(p, stream);
+    // Persistent workgroups (fwd_prefill_persist.hip) wherever every CU gets at least two 256-row
+    // blocks to chain: the seams between a CU's blocks then cost no memory round trip.  Measured on
+    // MI355X against the block kernels (interleaved, bf16, d = 128): b8 s4096 h32 causal 892 -> 961
+    // TFLOP/s, full 1013 -> 1077; b4 s8192 h32/8 causal 1010 -> 1060; b32 s512 h16 causal 477 -> 529;
+    // b16 s1024 h16 full 869 -> 960.
+    if (geo == VFA_GEO_PERSIST8) return run_fwd_prefill_persist(p, stream, 0);
+    if (geo == VFA_GEO_BLOCK8) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
+    return bf ? launch_prefill<128, true, 4>(p, stream) : launch_prefill<128, false, 4>(p, stream);
 }
 
 #elif defined(VFA_SPLIT_TU)
