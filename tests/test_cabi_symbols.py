@@ -115,6 +115,19 @@ def test_config1_fp32_cpu_through_the_api_matches_torch_sdpa():
     torch.manual_seed(0)
     b, s, h, d = 2, 128, 4, 64
     q, k, v = (torch.randn(b, s, h, d, dtype=torch.float32) for _ in range(3))
+    # opt-in: without it fp32 CPU tensors get the reference's error, like any non-CUDA input
+    with pytest.raises(RuntimeError, match="fp16 and bf16|must be on CUDA"):
+        fa.flash_attn_func(q, k, v)
+    prev = fa.enable_cpu_fp32(True)
+    try:
+        _config1_checks(fa, F, torch, q, k, v, b, s, h, d)
+        with pytest.raises(RuntimeError, match="forward only"):
+            fa.flash_attn_func(q.clone().requires_grad_(), k, v)
+    finally:
+        fa.enable_cpu_fp32(prev)
+
+
+def _config1_checks(fa, F, torch, q, k, v, b, s, h, d):
     out, lse, sdm = fa.flash_attn_func(q, k, v, return_attn_probs=True)
     ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
     assert out.dtype == torch.float32 and out.shape == q.shape

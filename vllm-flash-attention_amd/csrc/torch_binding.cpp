@@ -228,9 +228,8 @@ std::vector<Tensor> fwd(Tensor &q, const Tensor &k, const Tensor &v, OptTensor &
                         OptTensor &alibi_slopes_, const double p_dropout, const double softmax_scale,
                         bool is_causal, int64_t window_size_left, int64_t window_size_right,
                         const bool return_softmax, std::optional<at::Generator> gen_) {
-    if (!q.is_cuda() && q.scalar_type() == at::kFloat)
-        return fwd_cpu_fp32(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, window_size_left,
-                            window_size_right);
+    // (fp32 CPU tensors are rejected here like any other non-CUDA input, as the reference does
+    //  (flash_api.cpp:263-271); the host evaluation is the separate entry `fwd_cpu_fp32`)
     const int dt = dtype_code(q);
     TORCH_CHECK(k.scalar_type() == q.scalar_type(), "query and key must have the same dtype");
     TORCH_CHECK(v.scalar_type() == q.scalar_type(), "query and value must have the same dtype");
@@ -836,6 +835,17 @@ std::vector<Tensor> varlen_bwd(const Tensor &dout, const Tensor &q, const Tensor
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "FlashAttention (MI355X / gfx950)";
     m.def("fwd", &fwd, "Forward pass");
+    // No counterpart in the reference (which accepts fp16 / bf16 CUDA tensors only): a plain host
+    // loop for fp32 CPU tensors, forward only, for the one configuration of the benchmark list that
+    // runs without a GPU (batch 2, seqlen 128, 4 heads, head dim 64 against torch SDPA).  The Python
+    // package routes to it only when asked (vllm_flash_attn.enable_cpu_fp32).
+    m.def("fwd_cpu_fp32",
+          [](const Tensor &q, const Tensor &k, const Tensor &v, OptTensor out_, OptTensor alibi_slopes_, double p_dropout,
+             double softmax_scale, bool is_causal, int64_t wl, int64_t wr) {
+              TORCH_CHECK(!q.is_cuda() && q.scalar_type() == at::kFloat, "fwd_cpu_fp32 takes fp32 CPU tensors");
+              return fwd_cpu_fp32(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, wl, wr);
+          },
+          "Forward pass on fp32 CPU tensors (host loop, forward only)");
     m.def("varlen_fwd", &varlen_fwd, "Forward pass (variable length)");
     m.def("bwd", &bwd, "Backward pass");
     m.def("varlen_bwd", &varlen_bwd, "Backward pass (variable length)");

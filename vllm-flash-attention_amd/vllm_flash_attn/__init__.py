@@ -3,6 +3,7 @@
 __version__ = "2.5.8.post3"
 
 from vllm_flash_attn.flash_attn_interface import (  # noqa: F401
+    enable_cpu_fp32,
     flash_attn_func,
     flash_attn_kvpacked_func,
     flash_attn_qkvpacked_func,

@@ -15,8 +15,13 @@ Deliberate differences from the reference wrappers:
   * dropout_p > 0 and return_attn_probs work (the fork compiles dropout out, setup.py:204): the
     keep mask is the reference kernel's Philox pattern (dropout.h, philox.cuh) for the state drawn
     from torch's CUDA generator.
-There is no CPU or eager fallback: without the HIP extension the import fails.
+  * opt-in only: after `enable_cpu_fp32(True)` (or with VLLM_FLASH_ATTN_CPU_FP32=1 in the
+    environment) `flash_attn_func` evaluates fp32 CPU tensors with the extension's host loop, forward
+    only (inputs that require grad are refused) -- the benchmark list's CPU configuration.  Without
+    the opt-in CPU tensors raise the reference's "must be on CUDA" error.
+There is no CPU or eager fallback for the kernels: without the HIP extension the import fails.
 """
+import os
 from typing import Optional, Union
 
 import torch
@@ -37,9 +42,24 @@ def _last_dim_contiguous(x):
     return x.contiguous() if x is not None and x.stride(-1) != 1 else x
 
 
+_cpu_fp32 = os.environ.get("VLLM_FLASH_ATTN_CPU_FP32", "0") == "1"
+
+
+def enable_cpu_fp32(on=True):
+    """Opt in to (or out of) the host evaluation of fp32 CPU tensors in `flash_attn_func`
+    (forward only; no counterpart in the reference, whose extension rejects them).  Returns the
+    previous setting."""
+    global _cpu_fp32
+    prev, _cpu_fp32 = _cpu_fp32, bool(on)
+    return prev
+
+
 def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, alibi_slopes,
                         return_softmax, *, out=None):
     q, k, v = (_last_dim_contiguous(x) for x in (q, k, v))
+    if _cpu_fp32 and not q.is_cuda and q.dtype == torch.float32:
+        return tuple(flash_attn_cuda.fwd_cpu_fp32(q, k, v, out, alibi_slopes, dropout_p, softmax_scale, causal,
+                                                  window_size[0], window_size[1]))
     out, q, k, v, out_padded, softmax_lse, S_dmask, rng_state = flash_attn_cuda.fwd(
         q, k, v, out, alibi_slopes, dropout_p, softmax_scale, causal, window_size[0], window_size[1],
         return_softmax, None)
@@ -272,6 +292,10 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
     with return_attn_probs=True, (out, softmax_lse (batch_size, nheads, seqlen_q), S_dmask) where S_dmask
     is an empty tensor unless dropout_p > 0.
     Reference: :793-867."""
+    if _cpu_fp32 and not q.is_cuda and q.dtype == torch.float32 and torch.is_grad_enabled() \
+            and any(x.requires_grad for x in (q, k, v)):
+        raise RuntimeError("the fp32 CPU path of flash_attn_func is forward only: detach the inputs or call it "
+                           "under torch.no_grad() (the backward kernels run on CUDA tensors)")
     return FlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, alibi_slopes,
                                deterministic, return_attn_probs, out)
 
