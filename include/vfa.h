@@ -176,6 +176,15 @@ int vfa_num_splits_heuristic(int batch_nheads_mblocks, int num_sms, int num_n_bl
 int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, int max_seqlen_k,
                            int max_seqlen_q, int num_cus);
 
+/* The same for grouped query heads (num_heads > num_heads_k): up to 64 query rows the decode
+ * kernel packs the query heads of a KV head into the rows of one workgroup, so the work items the
+ * split count has to fill the GPU with are (batch, KV head, 32-row block of seqlen_q * group rows)
+ * -- this function counts them the way the kernel is launched; with num_heads == num_heads_k or
+ * more than 64 query rows it equals vfa_splitkv_num_splits.  What a caller that passes
+ * num_splits == 0 semantics (flash_api.cpp:207-210) should size its scratch with. */
+int vfa_decode_num_splits(int batch, int num_heads, int num_heads_k, int head_size, int max_seqlen_k,
+                          int max_seqlen_q, int num_cus);
+
 /* Elements of the fp32 dq_accum buffer of the reference's parameter block
  * (csrc/flash_attn/src/flash.h:153-156); this library does not need the buffer. */
 size_t vfa_bwd_dq_accum_elems(int b, int seqlen_q, int h, int d, int total_q_or_0);

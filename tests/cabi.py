@@ -68,6 +68,7 @@ def load(path):
     h.vfa_params_sizeof.restype = C.c_size_t
     h.vfa_num_splits_heuristic.argtypes = [_int] * 4
     h.vfa_splitkv_num_splits.argtypes = [_int] * 6
+    h.vfa_decode_num_splits.argtypes = [_int] * 7
     h.vfa_bwd_dq_accum_elems.argtypes = [_int] * 5
     h.vfa_bwd_dq_accum_elems.restype = C.c_size_t
     h.vfa_bwd_head_splits.argtypes = [_int] * 5

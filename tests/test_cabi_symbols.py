@@ -155,6 +155,24 @@ def _config1_checks(fa, F, torch, q, k, v, b, s, h, d):
     assert (out_w - ref_w).abs().max().item() <= 1e-5
 
 
+def test_decode_split_count_counts_packed_gqa_rows_like_the_launch():
+    """Grouped heads, few query tokens: the planner's work items are (batch, KV head, 32-row block of
+    seqlen_q * group rows), the decode kernel's grid; MHA and long queries keep the reference's count."""
+    import cabi
+    lib = cabi.lib()
+    cus = 256
+    for sq in (1, 4, 8, 9, 16, 33, 64):
+        for h, hk in ((32, 8), (16, 2), (8, 1)):
+            g = h // hk
+            mb = (sq * g + 31) // 32
+            want = min((8192 + 127) // 128, lib.vfa_num_splits_heuristic(2 * hk * mb, 2 * cus, (8192 + 127) // 128, 128))
+            assert lib.vfa_decode_num_splits(2, h, hk, 128, 8192, sq, cus) == want, (sq, h, hk)
+    assert lib.vfa_decode_num_splits(2, 8, 8, 128, 8192, 1, cus) == lib.vfa_splitkv_num_splits(2, 8, 128, 8192, 1, cus)
+    assert lib.vfa_decode_num_splits(2, 32, 8, 128, 8192, 200, cus) == lib.vfa_splitkv_num_splits(2, 32, 128, 8192, 200, cus)
+    # the case the old planner under-split: 16 tokens x 4 grouped heads = 64 rows = 2 blocks per KV head
+    assert lib.vfa_decode_num_splits(1, 32, 8, 128, 8192, 16, cus) > lib.vfa_splitkv_num_splits(1, 32, 128, 8192, 16, cus)
+
+
 def test_decode_split_count_never_exceeds_the_kernels_key_tiles():
     import cabi
     lib = cabi.lib()

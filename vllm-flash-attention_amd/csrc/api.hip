@@ -190,6 +190,21 @@ extern "C" int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, i
     return std::min(tiles, vfa_num_splits_heuristic(batch * num_heads * num_m_blocks, num_cus_ * 2, num_n_blocks, 128));
 }
 
+extern "C" int vfa_decode_num_splits(int batch, int num_heads, int num_heads_k, int head_size, int max_seqlen_k,
+                                     int max_seqlen_q, int num_cus_) {
+    const int ratio = (num_heads_k > 0 && num_heads % num_heads_k == 0) ? num_heads / num_heads_k : 1;
+    if (ratio <= 1 || max_seqlen_q > 64)
+        return vfa_splitkv_num_splits(batch, num_heads, head_size, max_seqlen_k, max_seqlen_q, num_cus_);
+    // run_fwd_splitkv / launch_decode_hpb: rows = seqlen_q * ratio in 32-row blocks, one (pair of)
+    // KV head(s) per workgroup; a two-head workgroup fills a CU like two one-head workgroups, so the
+    // count against 2 * CUs is per head either way
+    const int m_blocks = (max_seqlen_q * ratio + 31) / 32;
+    const int block_n = head_size <= 64 ? 256 : (head_size <= 128 ? 128 : 64);
+    const int num_n_blocks = (max_seqlen_k + block_n - 1) / block_n;
+    const int tiles = std::max(1, (max_seqlen_k + 127) / 128);
+    return std::min(tiles, vfa_num_splits_heuristic(batch * num_heads_k * m_blocks, num_cus_ * 2, num_n_blocks, 128));
+}
+
 static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
     hipStream_t stream = (hipStream_t)p->stream;
     hipError_t e;
@@ -364,10 +379,7 @@ extern "C" int vfa_mha_fwd_kvcache_noalloc(const vfa_params *p) {
     if (q.num_splits == 0) {
         // the count the allocating path's caller would pick (set_params_splitkv), lowered until the
         // partial results fit the static array
-        const int ratio = p->h / p->h_k;
-        q.num_splits = (ratio > 1 && p->seqlen_q * ratio <= 32)
-                           ? vfa_splitkv_num_splits(p->b, p->h_k, p->d, p->seqlen_k, 1, num_cus())
-                           : vfa_splitkv_num_splits(p->b, p->h, p->d, p->seqlen_k, p->seqlen_q, num_cus());
+        q.num_splits = vfa_decode_num_splits(p->b, p->h, p->h_k, p->d, p->seqlen_k, p->seqlen_q, num_cus());
         while (q.num_splits > 1 && split_scratch_floats(p, q.num_splits, nullptr) > cap) q.num_splits--;
     }
     if (q.num_splits > 1) {

@@ -82,12 +82,9 @@ struct SplitScratch { Tensor lse, out; };
 void plan_splits(vfa_params &P, SplitScratch &S, int num_splits, int64_t b, int64_t h, int64_t d,
                  int64_t sk, int64_t sq, const at::TensorOptions &opts) {
     if (num_splits < 1) {
-        // Grouped query heads over few query tokens run packed into the rows of their KV head (one
-        // workgroup per KV head): the work items the split count has to fill the GPU with are the
-        // KV heads, as for the folded single-token decode.
-        const int64_t ratio = P.h_k > 0 ? h / P.h_k : 1;
-        if (ratio > 1 && sq * ratio <= 32) num_splits = vfa_splitkv_num_splits(b, P.h_k, d, sk, 1, cu_count());
-        else num_splits = vfa_splitkv_num_splits(b, h, d, sk, sq, cu_count());
+        // Grouped query heads over few query tokens run packed into the rows of their KV head: the
+        // library counts the work items the way its decode kernel is launched.
+        num_splits = vfa_decode_num_splits(b, h, P.h_k > 0 ? P.h_k : h, d, sk, sq, cu_count());
     }
     TORCH_CHECK(num_splits <= 128, "num_splits > 128 not supported");
     P.num_splits = num_splits;
