@@ -110,6 +110,13 @@ typedef struct vfa_params {
      * the device for {seed, offset} (what the forward wrote), else philox_seed / philox_offset. */
     uint64_t philox_seed, philox_offset;
     uint64_t *rng_state;
+    /* Forward under graph capture: when philox_seed_ptr != NULL the kernel reads the seed from
+     * *philox_seed_ptr and the offset from *philox_offset_ptr + philox_offset_intragraph ON THE
+     * DEVICE, at replay time, instead of philox_seed / philox_offset -- the captured form of a
+     * generator's state (at::PhiloxCudaState; the reference passes it as params.philox_args,
+     * flash_api.cpp:388-394, and unpacks it in the kernel, flash_fwd_kernel.h:45). */
+    const int64_t *philox_seed_ptr, *philox_offset_ptr;
+    uint32_t philox_offset_intragraph;
     /* Return_softmax output (flash_fwd_kernel.h:326-334), forward with p_dropout > 0 only: 16-bit
      * (b, h, seqlen_q_rounded, seqlen_k_rounded), exp(score - running max) per 64-key tile with
      * the sign bit set on dropped entries; NULL = off.  Both rounded lengths are multiples of 128

@@ -44,6 +44,7 @@ class VfaParams(C.Structure):
         ("stream", _p),
         ("stage_events", _p),
         ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64), ("rng_state", _p),
+        ("philox_seed_ptr", _p), ("philox_offset_ptr", _p), ("philox_offset_intragraph", C.c_uint32),
         ("s_dmask", _p), ("seqlen_q_rounded", _int), ("seqlen_k_rounded", _int),
         ("bwd_head_splits", _int), ("bwd_part_rows", _i64), ("seqlen_ro", _int),
     ]

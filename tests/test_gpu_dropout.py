@@ -169,3 +169,49 @@ def test_dropout_rejections():
     assert torch.equal(a, b)
     c = fa.flash_attn_func(q, q, q, dropout_p=0.4)
     assert not torch.equal(a, c)
+
+
+def test_dropout_forward_backward_under_graph_capture():
+    """dropout_p > 0 inside a HIP graph: the generator hands out its CAPTURED state (device pointers
+    to seed and offset plus an offset inside the graph), the forward kernel unpacks it on the device
+    at replay time (flash_api.cpp:388-394, flash_fwd_kernel.h:45) and writes {seed, offset} to
+    rng_state for the backward.  Every replay draws a fresh mask; each replay's results equal an
+    eager call with the seed / offset that replay reported, bit for bit."""
+    import cabi
+    import vllm_flash_attn_2_cuda as ext
+    torch.manual_seed(5)
+    b, s, h, hk, d, pd = 2, 300, 4, 2, 128, 0.1
+    scale = d ** -0.5
+    q = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, s, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, s, hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+
+    def step():
+        res = ext.fwd(q, k, v, None, None, pd, scale, True, -1, -1, False, None)
+        out, lse, rng = res[0], res[5], res[7]
+        dq, dk, dv, _ = ext.bwd(do, q, k, v, out, lse, None, None, None, None, pd, scale, True, -1, -1, False, None, rng)
+        return out, lse, rng, dq, dk, dv
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = step()
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        out, lse, rng, dq, dk, dv = (t.clone() for t in cap)
+        seed, off = int(rng[0].item()), int(rng[1].item())
+        seen.append((seed, off))
+        eo, el = cabi.fwd(q, k, v, causal=True, p_dropout=pd, philox_seed=seed, philox_offset=off)
+        assert torch.equal(eo, out) and torch.equal(el, lse)
+        edq, edk, edv, _ = cabi.bwd(do, q, k, v, out, lse, causal=True, p_dropout=pd, philox_seed=seed, philox_offset=off)
+        assert torch.equal(edq, dq) and torch.equal(edk, dk) and torch.equal(edv, dv)
+    assert len(set(seen)) == 3, seen            # every replay advanced the generator
+    assert all(b_[1] - a_[1] >= b * h * 32 for a_, b_ in zip(seen, seen[1:]))

@@ -137,6 +137,8 @@ static void fill_common(const vfa_params *p, KParams &k, int seqlen_q_for_fold, 
     k.rp_dropout = 1.f / k.p_keep;
     k.scale_rp = p->p_dropout > 0.f ? k.rp_dropout * k.scale : k.scale;
     k.philox_seed = p->philox_seed; k.philox_offset = p->philox_offset;
+    k.seed_ptr = (const long long *)p->philox_seed_ptr; k.offset_ptr = (const long long *)p->philox_offset_ptr;
+    k.offset_intragraph = p->philox_offset_intragraph;
     k.rng_state = (unsigned long long *)p->rng_state;
 }
 

@@ -156,14 +156,21 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
-    if constexpr (DROP) {  // flash_fwd_kernel.h:51-54
-        if (blockIdx.x == 0 && tid == 0 && p.rng_state) {
-            p.rng_state[0] = p.philox_seed;
-            p.rng_state[1] = p.philox_offset;
+    // Philox state: the caller's values, or (under graph capture) read on the device at replay
+    // time from the generator's captured state (at::cuda::philox::unpack, flash_fwd_kernel.h:45)
+    unsigned long long ph_seed = p.philox_seed, ph_offset = p.philox_offset;
+    if constexpr (DROP) {
+        if (p.seed_ptr) {
+            ph_seed = (unsigned long long)*p.seed_ptr;
+            ph_offset = (unsigned long long)*p.offset_ptr + p.offset_intragraph;
+        }
+        if (blockIdx.x == 0 && tid == 0 && p.rng_state) {  // flash_fwd_kernel.h:51-54
+            p.rng_state[0] = ph_seed;
+            p.rng_state[1] = ph_offset;
         }
     }
     if (m_block * BM >= sq) return;
-    const unsigned long long drop_off = p.philox_offset + (unsigned long long)((bidb * p.h + bidh) * 32);  // dropout.h:21
+    const unsigned long long drop_off = ph_offset + (unsigned long long)((bidb * p.h + bidh) * 32);  // dropout.h:21
 
     // ---- key tile range: flash_fwd_kernel.h:59-67 ----
     int n_min = !p.is_local ? 0 : max(0, (m_block * BM + sk - sq - p.wl) / BN);
@@ -718,7 +725,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                      (((int64_t)bidb * p.h + bidh) * p.sq_rounded_p + q0w + r) * p.sk_rounded_p + c0 + 4 * hh;
 #pragma unroll
             for (int kb2 = 0; kb2 < 2; kb2++) {
-                const unsigned keep = keep_bits_qlane(p.philox_seed, drop_off, q0w >> 4, (c0 >> 5) + kb2,
+                const unsigned keep = keep_bits_qlane(ph_seed, drop_off, q0w >> 4, (c0 >> 5) + kb2,
                                                       r, hh, p.drop_keep_u8);
 #pragma unroll
                 for (int e = 0; e < 2; e++)

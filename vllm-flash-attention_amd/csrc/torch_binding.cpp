@@ -120,9 +120,17 @@ Tensor plan_dropout(vfa_params &P, double p_dropout, bool return_softmax, int64_
         auto gen = at::get_generator_or_default<at::CUDAGeneratorImpl>(
             gen_, at::cuda::detail::getDefaultCUDAGenerator());
         std::lock_guard<std::mutex> lock(gen->mutex_);
-        const auto seed_offset = gen->philox_engine_inputs((uint64_t)(b * h * 32));
-        P.philox_seed = seed_offset.first;
-        P.philox_offset = seed_offset.second;
+        // flash_api.cpp:388-394: under graph capture the state is a pair of device pointers plus an
+        // offset inside the graph, read by the kernel at replay time; otherwise plain values
+        const at::PhiloxCudaState st = gen->philox_cuda_state((uint64_t)(b * h * 32));
+        if (st.captured_) {
+            P.philox_seed_ptr = st.seed_.ptr;
+            P.philox_offset_ptr = st.offset_.ptr;
+            P.philox_offset_intragraph = st.offset_intragraph_;
+        } else {
+            P.philox_seed = st.seed_.val;
+            P.philox_offset = st.offset_.val;
+        }
     }
     return p;
 }

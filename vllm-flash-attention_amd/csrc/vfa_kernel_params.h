@@ -105,6 +105,8 @@ struct KParams {
     float p_keep;                // 1 - p_dropout
     float scale_rp;              // scale * rp_dropout
     unsigned long long philox_seed, philox_offset;
+    const long long *seed_ptr, *offset_ptr;   // forward: when non-null the state is read here on the device (graph capture)
+    unsigned offset_intragraph;
     unsigned long long *rng_state;   // fwd: written; bwd: read when non-null
     int rng_read;                // backward: take seed / offset from rng_state
     void *s_dmask;               // (b, h, sq_rounded_p, sk_rounded_p) 16-bit or null
