@@ -1315,8 +1315,9 @@ static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
 
 template <int DP, bool BF16, int NW, bool DROP>
 static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
-    if constexpr (DROP) {  // one variant (generic loads) per geometry
-        return launch_dkdv_impl<DP, BF16, NW, false, true>(p, stream);
+    if constexpr (DROP) {
+        return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true, true>(p, stream)
+                                  : launch_dkdv_impl<DP, BF16, NW, false, true>(p, stream);
     } else {
         return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
                                   : launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
@@ -1792,7 +1793,8 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         // 4-wave workgroups per CU, which overlap each other's prologues.
         const int geo_q = DROP ? VFA_GEO_BLOCK4 : dq_geometry(p, device_num_cus());
         if (geo_q == VFA_GEO_PERSIST8) e = run_bwd_dq_persist(p, stream);
-        else if constexpr (DROP) e = launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
+        else if constexpr (DROP) e = bwd_fits_buffer(p) ? launch_dq_impl<DP, BF16, 4, true, true>(p, stream)
+                                                        : launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
         else if constexpr (DP == 256) e = launch_dq<DP, BF16, 4>(p, stream);
         else e = geo_q == VFA_GEO_BLOCK8 ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;

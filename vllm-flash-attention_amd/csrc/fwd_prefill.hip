@@ -851,7 +851,6 @@ static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-#if !defined(VFA_DROPOUT_TU) || defined(VFA_SPLIT_TU)
 // Contiguous K/V whose per-(batch, head) extent fits a 32-bit buffer offset take the buffer-load path.
 static bool kv_fits_buffer(const KParams &p) {
     if (p.block_table) return false;
@@ -878,7 +877,6 @@ static bool paged_fits_direct(const KParams &p) {
            (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
 }
 
-#endif
 #if !defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)
 template <int DP, bool BF16, int NW>
 static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
@@ -947,15 +945,21 @@ hipError_t run_fwd_prefill_split(const KParams &p, hipStream_t stream) {
     return bf ? launch_prefill_split<256, true>(p, stream) : launch_prefill_split<256, false>(p, stream);
 }
 #else   // VFA_DROPOUT_TU: the dropout variants are compiled as a translation unit of their own
-// Dropout is a training feature: one geometry (4 waves, generic loads) per head dim.
+// Dropout is a training feature: one geometry (4 waves) per head dim; contiguous K/V that fit a
+// 32-bit buffer offset load straight into LDS at d <= 128, anything else by generic loads.
 hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
-    if (p.d <= 64)
+    const bool direct = kv_fits_buffer(p);
+    if (p.d <= 64) {
+        if (direct) return bf ? launch_prefill_impl<64, true, 4, 3, true>(p, stream) : launch_prefill_impl<64, false, 4, 3, true>(p, stream);
         return bf ? launch_prefill_impl<64, true, 4, 0, true>(p, stream)
                   : launch_prefill_impl<64, false, 4, 0, true>(p, stream);
-    if (p.d <= 128)
+    }
+    if (p.d <= 128) {
+        if (direct) return bf ? launch_prefill_impl<128, true, 4, 3, true>(p, stream) : launch_prefill_impl<128, false, 4, 3, true>(p, stream);
         return bf ? launch_prefill_impl<128, true, 4, 0, true>(p, stream)
                   : launch_prefill_impl<128, false, 4, 0, true>(p, stream);
+    }
     return bf ? launch_prefill_impl<256, true, 4, 0, true>(p, stream)
               : launch_prefill_impl<256, false, 4, 0, true>(p, stream);
 }
