@@ -1745,7 +1745,9 @@ hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream);  // bwd_dkdv_
 bool bwd_dkdv_w64_ok(const KParams &p) {
     return p.d <= 128 && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
 }
+bool bwd_dkdv_wide_ok(const KParams &p) { return p.d > 128 && p.hsplit <= 1 && bwd_fits_buffer(p); }
 #endif
+hipError_t run_bwd_dkdv_wide(const KParams &p, hipStream_t stream);  // bwd_dkdv_wide.hip
 bool bwd_dkdv_persist_ok(const KParams &p);                          // bwd_dkdv_persist.hip
 long long bwd_dkdv_persist_items(const KParams &p);
 hipError_t run_bwd_dkdv_persist(const KParams &p, hipStream_t stream);
@@ -1777,6 +1779,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
 #endif
     if (persist_kv) {}
     else if (geo_kv == VFA_GEO_WAVE64) e = run_bwd_dkdv_w64(p, stream);
+    else if (geo_kv == VFA_GEO_WIDE32) e = run_bwd_dkdv_wide(p, stream);
     else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
     else e = geo_kv == VFA_GEO_BLOCK4 ? launch_dkdv<DP, BF16, 4, DROP>(p, stream) : launch_dkdv<DP, BF16, 8, DROP>(p, stream);
     if (e != hipSuccess) return e;

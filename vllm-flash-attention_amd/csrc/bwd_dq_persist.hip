@@ -51,6 +51,9 @@ bwd_dq_persist_kernel(const KParams p, const int n_mblocks, const int n_items) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The later-dispatched wave of each SIMD loses the issue arbitration (by age) in every phase;
+    // a static priority for that half, set once, measured 0.4-1.1 % less time.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int r = lane & 31, hh = lane >> 5;
     const int r_ = r, hh_ = hh, lane_ = lane, tid_ = tid;   // (shadowed by opaque copies in the seam code)
     const int sq = p.seqlen_q, sk = p.seqlen_k;   // dense batch

@@ -58,6 +58,9 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The later-dispatched wave of each SIMD loses the issue arbitration (by age) in every phase;
+    // a static priority for that half, set once, measured 0.4-1.1 % less time.
+    if (NW_ > 4 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int r = lane & 31, hh = lane >> 5;
     const int sq = p.seqlen_q, sk = p.seqlen_k;   // dense batch: every entry has these lengths
     const float c2 = p.scale_log2;

@@ -28,6 +28,7 @@ namespace vfa {
 bool fwd_prefill_persist_ok(const KParams &p);   // fwd_prefill_persist.hip
 bool bwd_dq_persist_ok(const KParams &p);        // bwd_dq_persist.hip
 bool bwd_dkdv_w64_ok(const KParams &p);          // bwd.hip
+bool bwd_dkdv_wide_ok(const KParams &p);         // bwd.hip
 
 // keys a row block can see under a sliding window: the window's span, not the sequence
 inline int64_t visible_span(const KParams &p) {
@@ -73,9 +74,11 @@ inline int dq_geometry(const KParams &p, const int cus) {
     return big ? VFA_GEO_BLOCK8 : VFA_GEO_BLOCK4;
 }
 
-// dK/dV (bwd_dkdv_kernel / bwd_dkdv_w64_kernel), no dropout.
+// dK/dV (bwd_dkdv_kernel / bwd_dkdv_w64_kernel / bwd_dkdv_wide_kernel), no dropout.
 inline int dkdv_geometry(const KParams &p, const int cus) {
-    if (p.d > 128) return VFA_GEO_BLOCK4;
+    // d > 128: one workgroup for all 256 columns (8 products per key block and slice) wherever it
+    // runs; else the head dim cut in two column halves (12 products; development switch 0 = 5)
+    if (p.d > 128) return (g_tuning[0] != 5 && bwd_dkdv_wide_ok(p)) ? VFA_GEO_WIDE32 : VFA_GEO_BLOCK4;
     const bool w64_ok = bwd_dkdv_w64_ok(p);
     if (g_tuning[0] == 2 && w64_ok) return VFA_GEO_WAVE64;
     if (g_tuning[0] == 1) return VFA_GEO_BLOCK8;
