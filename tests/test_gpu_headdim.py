@@ -153,8 +153,11 @@ WIDE = [
 
 @pytest.mark.parametrize("case", WIDE, ids=[str(c) for c in WIDE])
 def test_wide_head_dim_fwd_bwd_vs_oracle(case):
-    """d in {160, 192, 224, 256}: the DP = 256 instantiations (4-wave workgroups, generic loads in
-    the dK/dV kernel), forward and backward against the oracle."""
+    """d in {160, 192, 224, 256}: the DP = 256 instantiations, forward and backward against the
+    oracle.  The dK/dV kernel of the shipped dispatch keeps all 256 columns of 32 keys per wave in
+    one workgroup (bwd_dkdv_wide.hip); the kernel that cuts the head dim in two column halves
+    (what a head split, dropout or 64-bit offsets still take) is checked on the same inputs through
+    the development library (switch 0 = 5)."""
     import cabi
     from oracle import fa_oracle
     from gpu_util import TDT, f32, ulp_tol
@@ -170,9 +173,49 @@ def test_wide_head_dim_fwd_bwd_vs_oracle(case):
     out, lse = cabi.fwd(q, k, v, **kw)[:2]
     ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), **okw)
     assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
-    grads = cabi.bwd(do, q, k, v, out, lse, **kw)[:3]
+    grads = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
     ref = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), ro, rl, **okw)[:3]
     _check_grads(grads, ref, dt)
+    with cabi.dev(0, 5):
+        halves = cabi.bwd(do, q, k, v, out, lse, head_splits=1, **kw)[:3]
+    _check_grads(halves, ref, dt)
+    assert torch.equal(grads[0], halves[0])   # (dQ: the same kernel on the same inputs)
+
+
+def test_wide_head_dim_many_steps_grouped_heads_and_ragged_batch():
+    """The one-workgroup dK/dV kernel at d = 256 over several key blocks and many 32-row steps:
+    a dense causal batch with grouped heads against the column-halves kernel (the same products
+    accumulated in the same order over k-steps, slices and heads: bitwise equal), and a ragged
+    batch with very short sequences against the oracle."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import f32
+    torch.manual_seed(5)
+    b, s, h, hk, d = 2, 1200, 6, 2, 256
+    q = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, s + 77, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    out, lse = cabi.fwd(q, k, v, causal=True)[:2]
+    g = cabi.bwd(do, q, k, v, out, lse, causal=True, head_splits=1)[:3]
+    with cabi.dev(0, 5):
+        g0 = cabi.bwd(do, q, k, v, out, lse, causal=True, head_splits=1)[:3]
+    for a, a0 in zip(g, g0):
+        assert not torch.isnan(a).any()
+        assert torch.equal(a, a0)
+    ql, kl = [700, 37, 1, 300], [650, 37, 5, 460]
+    h, hk, d = 2, 1, 192
+    q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.float16)
+    k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.float16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    cq, ck = _cu(ql), _cu(kl)
+    vk = dict(cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+    out, lse = cabi.fwd(q, k, v, causal=True, **vk)[:2]
+    g = cabi.bwd(do, q, k, v, out, lse, causal=True, head_splits=1, **vk)[:3]
+    nk = dict(cu_seqlens_q=cq.cpu().numpy(), cu_seqlens_k=ck.cpu().numpy(), max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+    ref = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), f32(out), f32(lse), dtype="fp16", causal=True, **nk)[:3]
+    _check_grads(g, ref, "fp16")
 
 
 @pytest.mark.parametrize("paged", [False, True])
