@@ -210,7 +210,8 @@ int vfa_bwd_head_splits(int batch, int num_heads, int num_heads_k, int max_seqle
 #define VFA_GEO_BLOCK8 8     /* one 8-wave workgroup per 256-row (256-key) block */
 #define VFA_GEO_PERSIST8 18  /* one 8-wave workgroup per CU walks 256-row blocks */
 #define VFA_GEO_WAVE64 64    /* dK/dV: 4 waves x 64 keys, one wave per SIMD */
-#define VFA_GEO_WIDE32 32    /* dK/dV at d > 128: 4 waves x 32 keys x all 256 columns, one wave per SIMD */
+#define VFA_GEO_WIDE32 32    /* d > 128: 4 waves at one wave per SIMD, accumulators at fixed registers (forward: 32 rows per
+                                wave, hand-pipelined; dK/dV: 32 keys x all 256 columns per wave) */
 int vfa_dispatch_geometry(const vfa_params *p, int kernel);
 
 /* sizeof(vfa_params) of the built library, for foreign-function bindings to check their mirror of

@@ -56,8 +56,8 @@ CASES = [
     ((8, 2048, 2048, 32, 32, 128, False), (P8, B8, P8)),     # the 64-key dK/dV kernel from 3072 keys
     ((4, 2048, 2048, 16, 16, 64, True), (B4, B8, B4)),       # d = 64: 4 waves forward / dQ, 8 waves dK/dV
     ((8, 4096, 4096, 32, 32, 64, False), (B4, B8, B4)),
-    ((4, 4096, 4096, 16, 16, 256, True), (B4, WIDE, B4)),    # d = 256: one wave per SIMD; dK/dV keeps all 256 columns in one workgroup
-    ((1, 300, 520, 8, 2, 160, False), (B4, WIDE, B4)),
+    ((4, 4096, 4096, 16, 16, 256, True), (WIDE, WIDE, B4)),  # d = 256: one wave per SIMD; hand-pipelined forward, dK/dV with all 256 columns in one workgroup
+    ((1, 300, 520, 8, 2, 160, False), (WIDE, WIDE, B4)),
     ((4, 4096, 4096, 32, 8, 128, True), (P8, B8, P8)),       # grouped heads: 256-key blocks counted per KV head
 ]
 
@@ -78,6 +78,8 @@ def test_problems_the_walk_does_not_take_fall_back_to_block_kernels():
     # head split (few (batch, KV head, key block) items, grouped heads): the split multiplies the items
     assert _geo(DKDV, 1, 8192, 8192, 16, 2, 128, True, head_splits=8) == B8
     assert _geo(DKDV, 1, 8192, 8192, 16, 2, 128, True) == B4
+    # d > 128 with ALiBi: the forward's general kernel
+    assert _geo(FWD, 4, 4096, 4096, 16, 16, 256, True, alibi=True) == B4
     # d > 128 with a head split: the column-halves kernel (it writes the fp32 partial slabs)
     assert _geo(DKDV, 1, 8192, 8192, 16, 2, 256, True, head_splits=8) == B4
 

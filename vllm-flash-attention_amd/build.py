@@ -26,7 +26,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
                "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip", "fwd_prefill_persist.hip", "bwd_dq_persist.hip",
-               "bwd_dkdv_wide.hip"]
+               "bwd_dkdv_wide.hip", "fwd_prefill_wide.hip"]
 # The development library (libvfa_hip_dev.so, -DVFA_DEV) adds the kernels no shipped dispatch takes
 # and the kernel-variant switches (vfa_debug_set_tuning) that select them; the A/B tools and the
 # tests that check a shipped kernel against its alternative load it.  The product never does.
@@ -36,6 +36,7 @@ DEV_LIB = os.path.join(HERE, "libvfa_hip_dev.so")
 # consume must be allocated in the arch VGPRs, not forced into the accumulator half of the file.
 EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "bwd_dkdv_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "fwd_prefill_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "fwd_prefill_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # The persistent dQ kernel under LLVM's ILP-first scheduler: the default one puts every LDS
                # read directly in front of its MFMA (read, wait, MFMA, read, wait, ...); this one issues

@@ -899,6 +899,7 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 bool fwd_prefill_w64_ok(const KParams &p);
 hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
+hipError_t run_fwd_prefill_wide(const KParams &p, hipStream_t stream);       // fwd_prefill_wide.hip
 long long fwd_prefill_persist_items(const KParams &p, int waves_override);   // fwd_prefill_persist.hip
 hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream, int waves_override);
 
@@ -915,6 +916,7 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     // the geometry: vfa_dispatch.h (work per CU first, keys per block second)
     const int geo = fwd_geometry(p, device_num_cus());
     if (p.d <= 64) return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
+    if (geo == VFA_GEO_WIDE32) return run_fwd_prefill_wide(p, stream);
     if (p.d > 128) return bf ? launch_prefill<256, true, 4>(p, stream) : launch_prefill<256, false, 4>(p, stream);
     // Persistent workgroups (fwd_prefill_persist.hip) wherever every CU gets at least two 256-row
     // blocks to chain: the seams between a CU's blocks then cost no memory round trip.  Measured on

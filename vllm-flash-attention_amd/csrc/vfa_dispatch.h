@@ -26,6 +26,7 @@
 namespace vfa {
 
 bool fwd_prefill_persist_ok(const KParams &p);   // fwd_prefill_persist.hip
+bool fwd_prefill_wide_ok(const KParams &p);      // fwd_prefill_wide.hip
 bool bwd_dq_persist_ok(const KParams &p);        // bwd_dq_persist.hip
 bool bwd_dkdv_w64_ok(const KParams &p);          // bwd.hip
 bool bwd_dkdv_wide_ok(const KParams &p);         // bwd.hip
@@ -44,7 +45,9 @@ inline long long key_blocks_256(const KParams &p) {
 
 // Forward (fwd_prefill_kernel / fwd_prefill_persist_kernel), no dropout.
 inline int fwd_geometry(const KParams &p, const int cus) {
-    if (p.d <= 64 || p.d > 128) return VFA_GEO_BLOCK4;   // d <= 64: softmax-bound, 4 waves everywhere (+8..40 %); d > 128: one wave per SIMD
+    if (p.d <= 64) return VFA_GEO_BLOCK4;   // softmax-bound, 4 waves everywhere (+8..40 %)
+    // d > 128: one wave per SIMD; the hand-pipelined kernel wherever it runs (development switch 4 = 2: never)
+    if (p.d > 128) return (g_tuning[4] != 2 && fwd_prefill_wide_ok(p)) ? VFA_GEO_WIDE32 : VFA_GEO_BLOCK4;
     const long long blocks = row_blocks_256(p);
     const bool masked = p.is_causal || p.is_local;
     // (without a mask the walk is ahead of the block kernel from one block per CU: b1 h8 s8192 0.262 -> 0.253 ms)

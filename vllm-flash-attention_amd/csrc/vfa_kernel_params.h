@@ -20,7 +20,8 @@ namespace vfa {
 //   [2] bit 0 inverts the decode kernel's choice of block-id regrouping over the XCDs, bit 1 turns off
 //       the packing of grouped query heads into the rows of their KV head
 //   [3] persistent forward / dQ workgroups: 1 = never, 2 = wherever the kernels can run
-//   [4] forward at 64 < d <= 128: 1 = the 64-rows-per-wave kernel wherever it applies
+//   [4] forward at 64 < d <= 128: 1 = the 64-rows-per-wave kernel wherever it applies; at d > 128:
+//       2 = never the hand-pipelined kernel (fwd_prefill_wide.hip)
 //   [5] paged prefill: 1 = per-page descriptors through staging registers instead of straight into LDS
 //   [6] forward at d = 128: 1 = 8 waves, 2 = 4 waves;  [7] the same for the dQ kernel
 #ifdef VFA_DEV
