@@ -74,7 +74,13 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <bool BF16>
+// PAGED: K/V through a block table whose pages are a power of two and a multiple of 16 rows.  A wave
+// then fills 16 consecutive rows of a tile -- they lie in one page and share a descriptor, built in
+// scalar registers from a page id that was requested one iteration earlier -- and a lane's chunk
+// in instruction i is its chunk in instruction 0 XOR a constant (the swizzle is linear in the
+// row's bits).  Chunks in the head-dim padding are redirected to the last real chunk: they meet zero
+// columns of Q (K) or columns of O that are never stored (V), and finite data stays finite.
+template <bool BF16, bool PAGED>
 __global__ void __launch_bounds__(256, 1)
 fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
     using namespace fw256;
@@ -114,10 +120,17 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
 
     // ---- K/V: contiguous per (batch, head), fetched straight into LDS ----
     const int bidb_cache = p.cache_batch_idx ? p.cache_batch_idx[bidb] : bidb;
-    const unsigned short *kg = (const unsigned short *)p.k + (int64_t)hk * p.k_hs + bi.k_off(p.k_bs, p.k_rs, bidb_cache);
-    const unsigned short *vg = (const unsigned short *)p.v + (int64_t)hk * p.v_hs + bi.k_off(p.v_bs, p.v_rs, bidb_cache);
-    const i32x4 k_rsrc = make_rsrc(kg, (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2));
-    const i32x4 v_rsrc = make_rsrc(vg, (unsigned)(((int64_t)(sk - 1) * p.v_rs + p.d) * 2));
+    const unsigned short *kg = (const unsigned short *)p.k + (int64_t)hk * p.k_hs;
+    const unsigned short *vg = (const unsigned short *)p.v + (int64_t)hk * p.v_hs;
+    const int *bt = nullptr;
+    if constexpr (PAGED) {
+        bt = p.block_table + (int64_t)bidb * p.bt_bs;
+    } else {
+        kg += bi.k_off(p.k_bs, p.k_rs, bidb_cache);
+        vg += bi.k_off(p.v_bs, p.v_rs, bidb_cache);
+    }
+    const i32x4 k_rsrc = make_rsrc(kg, PAGED ? 0u : (unsigned)(((int64_t)(sk - 1) * p.k_rs + p.d) * 2));
+    const i32x4 v_rsrc = make_rsrc(vg, PAGED ? 0u : (unsigned)(((int64_t)(sk - 1) * p.v_rs + p.d) * 2));
     const i32x4 k_rsrc_none = make_rsrc(kg, 0u);  // every lane out of range: the load writes zeros
     // A wave instruction fills 1 KiB of LDS in lane order = 2 rows of the tile; lane -> the chunk the
     // XOR swizzle places at its slot.  The rows of a wave's instructions are 8 apart: the lane's
@@ -138,31 +151,76 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
     }
     const unsigned k_rs2 = (unsigned)p.k_rs * 2, v_rs2 = (unsigned)p.v_rs * 2;
     const unsigned lds0 = 0;  // the dynamic LDS segment starts at LDS address 0 (no static LDS here)
-    auto dma_k = [&](const int n, const int slot, const int i, const bool exists = true) __attribute__((always_inline)) {
-        const unsigned rows = (unsigned)(n * BN + RPI * NW * i);
-        i32x4 rs;  // (a tile that does not exist is fetched through the empty descriptor: no branch in the loop)
-#pragma unroll
-        for (int t = 0; t < 4; t++) rs[t] = exists ? k_rsrc[t] : k_rsrc_none[t];
-        dma_16b_to_lds(rs, dk_voff[i & 1] + rows * k_rs2, lds0 + slot * TILE + (wave + NW * i) * 1024);
+    // PAGED: the lane's column in instruction 0 of its wave's 16-row group, and its row part
+    const unsigned pcol0 = (unsigned)(((lane % CPR) ^ swz<DP>(lane / CPR)) << 4);
+    const unsigned pcol_max = (unsigned)(p.d / 8 - 1) * 16u;
+    const unsigned prow_k = (unsigned)(lane / CPR) * k_rs2, prow_v = (unsigned)(lane / CPR) * v_rs2;
+    // page ids (scalar) of this wave's row group in tiles n, n - 1, n - 2 of the current iteration
+    int pq0 = 0, pq1 = 0, pq2 = 0;
+    auto page_of = [&](const int n) __attribute__((always_inline)) -> int {
+        const int rb = n * BN + 16 * wave;
+        return bt[(rb >= 0 && rb < sk) ? rb >> p.page_shift : 0];
     };
-    auto dma_v = [&](const int n, const int slot, const int i) __attribute__((always_inline)) {
-        const unsigned rows = (unsigned)(n * BN + RPI * NW * i);
-        dma_16b_to_lds(v_rsrc, dv_voff[i & 1] + rows * v_rs2, lds0 + (3 + slot) * TILE + (wave + NW * i) * 1024);
+    auto page_rsrc = [&](const unsigned short *base, const int64_t bs, const int64_t rs, const int pg, const int n,
+                         const bool exists) __attribute__((always_inline)) -> i32x4 {
+        const int rb = n * BN + 16 * wave;
+        const int valid = exists ? min(sk - rb, 16) : 0;  // rows of the group that exist
+        return make_rsrc(base + (int64_t)pg * bs + (int64_t)(rb & (p.page_size - 1)) * rs,
+                         valid > 0 ? (unsigned)(((int64_t)(valid - 1) * rs + p.d) * 2) : 0u);
+    };
+    // The descriptors and row bases of an iteration's loads: K tile n - 2 (none: the empty descriptor,
+    // no branch in the loop) and V tile n.
+    struct Loads { i32x4 kr, vr; unsigned kbase, vbase; };
+    auto begin_loads = [&](const int it) __attribute__((always_inline)) -> Loads {
+        const int n = n_max - 1 - it;
+        const bool k_next = n - 2 >= n_min;
+        Loads L;
+        if constexpr (PAGED) {
+            L.kr = page_rsrc(kg, p.k_bs, p.k_rs, pq2, n - 2, k_next);
+            L.vr = page_rsrc(vg, p.v_bs, p.v_rs, pq0, n, true);
+            L.kbase = 0;
+            L.vbase = 0;
+            pq0 = pq1;
+            pq1 = pq2;
+            pq2 = page_of(n - 3);  // (used in the next iteration)
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) L.kr[t] = k_next ? k_rsrc[t] : k_rsrc_none[t];
+            L.vr = v_rsrc;
+            L.kbase = (unsigned)((n - 2) * BN) * k_rs2;
+            L.vbase = (unsigned)(n * BN) * v_rs2;
+        }
+        return L;
+    };
+    auto pcol = [&](const int i) __attribute__((always_inline)) -> unsigned {
+        return min(pcol0 ^ (unsigned)(swz<DP>(RPI * i) << 4), pcol_max);
+    };
+    auto dma_k = [&](const Loads &L, const int slot, const int i) __attribute__((always_inline)) {
+        if constexpr (PAGED)
+            dma_16b_to_lds(L.kr, pcol(i) + prow_k + (unsigned)(RPI * i) * k_rs2, lds0 + slot * TILE + wave * 8192 + i * 1024);
+        else
+            dma_16b_to_lds(L.kr, dk_voff[i & 1] + L.kbase + (unsigned)(RPI * NW * i) * k_rs2, lds0 + slot * TILE + (wave + NW * i) * 1024);
+    };
+    auto dma_v = [&](const Loads &L, const int slot, const int i) __attribute__((always_inline)) {
+        if constexpr (PAGED)
+            dma_16b_to_lds(L.vr, pcol(i) + prow_v + (unsigned)(RPI * i) * v_rs2, lds0 + (3 + slot) * TILE + wave * 8192 + i * 1024);
+        else
+            dma_16b_to_lds(L.vr, dv_voff[i & 1] + L.vbase + (unsigned)(RPI * NW * i) * v_rs2, lds0 + (3 + slot) * TILE + (wave + NW * i) * 1024);
+    };
+    // a K tile outside the pipeline (the prologue's two)
+    auto load_k_now = [&](const int n, const int slot) __attribute__((always_inline)) {
+        Loads L;
+        if constexpr (PAGED) {
+            L.kr = page_rsrc(kg, p.k_bs, p.k_rs, page_of(n), n, true);
+            L.kbase = 0;
+        } else {
+            L.kr = k_rsrc;
+            L.kbase = (unsigned)(n * BN) * k_rs2;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) dma_k(L, slot, i);
     };
 
-    // ---- Q fragments (B operand of S^T = K Q^T) into a[128:191]: fragment s, lane (r, hh) holds
-    // Q[q0w + r][16 s + 8 hh ..] ----
-    {
-        const int row = q0w + r;
-        const bool rok = row < sq;
-        const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
-        static_for<KS>([&](auto S_) {
-            constexpr int s_ = decltype(S_)::value;
-            const int col = 16 * s_ + 8 * hh;
-            const i32x4 v = (rok && col < p.d) ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
-            q_write<s_>(v);
-        });
-    }
     static_for<8>([&](auto T) { o_zero<decltype(T)::value>(); });  // O^T tile db
     float m_run = -INFINITY;  // reference point of the exponentials, followed lazily
     float l_run = 0.f;        // running row sum, partial per lane half
@@ -296,13 +354,11 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
     // iterations ahead), V tiles through two (fetched in the iteration of their S, used by the P V of
     // the next one).
     auto issue_loads = [&](const int it) __attribute__((always_inline)) {
-        const int n = n_max - 1 - it;
-        if (n - 2 >= n_min) {
+        const Loads L = begin_loads(it);
 #pragma unroll
-            for (int i = 0; i < NI; i++) dma_k(n - 2, (it + 2) % 3, i);
-        }
+        for (int i = 0; i < NI; i++) dma_k(L, (it + 2) % 3, i);
 #pragma unroll
-        for (int i = 0; i < NI; i++) dma_v(n, it & 1, i);
+        for (int i = 0; i < NI; i++) dma_v(L, it & 1, i);
     };
     auto end_iteration = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the loads is in LDS
@@ -328,11 +384,27 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
     };
 
     // ---- prologue: K of the first two tiles ----
+    load_k_now(n_max - 1, 0);
+    if (n_it > 1) load_k_now(n_max - 2, 1);
+    // ---- Q fragments (B operand of S^T = K Q^T) into a[128:191]: fragment s, lane (r, hh) holds
+    // Q[q0w + r][16 s + 8 hh ..].  All sixteen requests go out behind the first K tiles' (one memory
+    // round trip for the lot), then they are moved to their registers. ----
+    {
+        const int row = q0w + r;
+        const bool rok = row < sq;
+        const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+        i32x4 qv[KS];
 #pragma unroll
-    for (int i = 0; i < NI; i++) dma_k(n_max - 1, 0, i);
-    if (n_it > 1) {
-#pragma unroll
-        for (int i = 0; i < NI; i++) dma_k(n_max - 2, 1, i);
+        for (int s_ = 0; s_ < KS; s_++) {
+            const int col = 16 * s_ + 8 * hh;
+            qv[s_] = (rok && col < p.d) ? *(const i32x4 *)(qr + col) : i32x4{0, 0, 0, 0};
+        }
+        static_for<KS>([&](auto S_) { q_write<decltype(S_)::value>(qv[decltype(S_)::value]); });
+    }
+    if constexpr (PAGED) {
+        pq0 = page_of(n_max - 1);
+        pq1 = page_of(n_max - 2);
+        pq2 = page_of(n_max - 3);
     }
     end_iteration();
 
@@ -371,8 +443,8 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
             const int kslot = it_ % 3;
             const char *kb = smem + kslot * TILE;
             const char *vb = smem + (3 + (PAR ^ 1)) * TILE;
-            const bool k_next = n - 2 >= n_min;
             const int kslot_next = kslot == 0 ? 2 : kslot - 1;  // (it_ + 2) % 3
+            const Loads L = begin_loads(it_);
             // ---- phase 1: S(n) | second half of softmax(n + 1) | the loads of this iteration ----
             constexpr int RING = WIDE_RING;  // fragments read ahead of their MFMAs (+1)
             i32x4 kfr[RING];
@@ -391,8 +463,8 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
                 }
                 if constexpr ((st & 1) == 0) {
                     constexpr int i = st >> 1;
-                    if constexpr (i < NI) dma_k(n - 2, kslot_next, i, k_next);
-                    else dma_v(n, PAR, i - NI);
+                    if constexpr (i < NI) dma_k(L, kslot_next, i);
+                    else dma_v(L, PAR, i - NI);
                 }
                 if constexpr (st + 1 < 2 * KS) ready(kfr[(st + 1) % RING]);  // (after this step's vector work)
             });
@@ -486,8 +558,11 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
 // Whether this kernel takes the call: head dims 129..256, K/V contiguous per (batch, head) within a
 // 32-bit buffer offset, no ALiBi (the caller checks dropout and split).
 bool fwd_prefill_wide_ok(const KParams &p) {
-    if (p.d <= 128 || p.d > 256 || p.block_table || p.alibi_slopes) return false;
+    if (p.d <= 128 || p.d > 256 || p.alibi_slopes) return false;
     const int64_t lim = (int64_t)1 << 30;
+    if (p.block_table)   // pages: a power of two, whole 16-row groups, 32-bit offsets inside a page
+        return p.page_shift >= 0 && p.page_size % 16 == 0 && (int64_t)p.page_size * p.k_rs * 2 < lim &&
+               (int64_t)p.page_size * p.v_rs * 2 < lim;
     const int64_t rows = (int64_t)p.seqlen_k + 256;
     return rows * p.k_rs * 2 < lim && rows * p.v_rs * 2 < lim;
 }
@@ -496,17 +571,15 @@ hipError_t run_fwd_prefill_wide(const KParams &p, hipStream_t stream) {
     const int n_mblocks = (p.seqlen_q + fw256::BM - 1) / fw256::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    static std::atomic<uint64_t> lds_set_bf{0}, lds_set_fp{0};
-    if (p.is_bf16) {
-        auto kern = fwd_prefill_wide_kernel<true>;
-        if (hipError_t e = set_dyn_lds_once((const void *)kern, fw256::LDS_BYTES, lds_set_bf); e != hipSuccess) return e;
+    static std::atomic<uint64_t> lds_set[4];
+    auto launch = [&](auto kern, std::atomic<uint64_t> &flag) -> hipError_t {
+        if (hipError_t e = set_dyn_lds_once((const void *)kern, fw256::LDS_BYTES, flag); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), fw256::LDS_BYTES, stream, p, n_mblocks);
-    } else {
-        auto kern = fwd_prefill_wide_kernel<false>;
-        if (hipError_t e = set_dyn_lds_once((const void *)kern, fw256::LDS_BYTES, lds_set_fp); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), fw256::LDS_BYTES, stream, p, n_mblocks);
-    }
-    return hipGetLastError();
+        return hipGetLastError();
+    };
+    if (p.block_table)
+        return p.is_bf16 ? launch(fwd_prefill_wide_kernel<true, true>, lds_set[0]) : launch(fwd_prefill_wide_kernel<false, true>, lds_set[1]);
+    return p.is_bf16 ? launch(fwd_prefill_wide_kernel<true, false>, lds_set[2]) : launch(fwd_prefill_wide_kernel<false, false>, lds_set[3]);
 }
 
 }  // namespace vfa
