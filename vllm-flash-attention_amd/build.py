@@ -26,7 +26,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
                "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip", "fwd_prefill_persist.hip", "bwd_dq_persist.hip",
-               "bwd_dkdv_wide.hip", "fwd_prefill_wide.hip", "bwd_dq_wide.hip"]
+               "bwd_dkdv_wide.hip", "fwd_prefill_wide.hip", "bwd_dq_ilp.hip"]
 # The development library (libvfa_hip_dev.so, -DVFA_DEV) adds the kernels no shipped dispatch takes
 # and the kernel-variant switches (vfa_debug_set_tuning) that select them; the A/B tools and the
 # tests that check a shipped kernel against its alternative load it.  The product never does.
@@ -45,10 +45,10 @@ EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # one-block-per-workgroup kernel 1.554.  The same flag costs the persistent forward 8 %
                # and makes the dK/dV kernels spill.
                "bwd_dq_persist.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
-               # the d > 128 dQ kernel (one wave per SIMD): 1.075 -> 0.953 ms at b4 s4096 h16 d256 causal
-               "bwd_dq_wide.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+               # the one-block-per-workgroup dQ kernels at d >= 128 (d256: 1.075 -> 0.953 ms at b4 s4096 h16 causal)
+               "bwd_dq_ilp.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 # the dropout translation units are one-line includes of the kernel sources
-EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"], "bwd_dq_wide.hip": ["bwd.hip"],
+EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"], "bwd_dq_ilp.hip": ["bwd.hip"],
               "fwd_prefill_split.hip": ["fwd_prefill.hip"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-I", INCLUDE, "-I", CSRC]

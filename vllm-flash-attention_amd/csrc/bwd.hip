@@ -33,7 +33,7 @@
 
 namespace vfa {
 
-#if defined(VFA_STAMP) && (defined(VFA_DROPOUT_TU) || defined(VFA_DQ256_TU))
+#if defined(VFA_STAMP) && (defined(VFA_DROPOUT_TU) || defined(VFA_DQ_ILP_TU))
 #undef VFA_STAMP
 #endif
 #ifdef VFA_STAMP
@@ -1740,7 +1740,7 @@ static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
 }
 
 hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream);  // bwd_dkdv_w64.hip
-#if !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ256_TU)
+#if !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ_ILP_TU)
 // Whether the 64-keys-per-wave dK/dV kernel can run this problem.
 bool bwd_dkdv_w64_ok(const KParams &p) {
     return p.d <= 128 && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
@@ -1748,7 +1748,7 @@ bool bwd_dkdv_w64_ok(const KParams &p) {
 bool bwd_dkdv_wide_ok(const KParams &p) { return p.d > 128 && p.hsplit <= 1 && bwd_fits_buffer(p); }
 #endif
 hipError_t run_bwd_dkdv_wide(const KParams &p, hipStream_t stream);  // bwd_dkdv_wide.hip
-hipError_t run_bwd_dq_256(const KParams &p, hipStream_t stream);     // bwd_dq_wide.hip (this file, other compiler flags)
+hipError_t run_bwd_dq_ilp(const KParams &p, hipStream_t stream, bool waves8);   // bwd_dq_ilp.hip (this file, other compiler flags)
 bool bwd_dkdv_persist_ok(const KParams &p);                          // bwd_dkdv_persist.hip
 long long bwd_dkdv_persist_items(const KParams &p);
 hipError_t run_bwd_dkdv_persist(const KParams &p, hipStream_t stream);
@@ -1799,7 +1799,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
         if (geo_q == VFA_GEO_PERSIST8) e = run_bwd_dq_persist(p, stream);
         else if constexpr (DROP) e = bwd_fits_buffer(p) ? launch_dq_impl<DP, BF16, 4, true, true>(p, stream)
                                                         : launch_dq_impl<DP, BF16, 4, false, true>(p, stream);
-        else if constexpr (DP == 256) e = run_bwd_dq_256(p, stream);
+        else if constexpr (DP >= 128) e = run_bwd_dq_ilp(p, stream, geo_q == VFA_GEO_BLOCK8);
         else e = geo_q == VFA_GEO_BLOCK8 ? launch_dq<DP, BF16, 8>(p, stream) : launch_dq<DP, BF16, 4>(p, stream);
         if (e != hipSuccess) return e;
     }
@@ -1807,14 +1807,19 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     return hipGetLastError();
 }
 
-#if defined(VFA_DQ256_TU)
-// The dQ kernel at d > 128 (4 waves at one wave per SIMD), a translation unit of its own
-// (bwd_dq_wide.hip) because it is built under LLVM's ILP-first scheduler: with a single wave per SIMD
-// nothing hides an LDS read placed right in front of its MFMA, which is where the default
-// scheduler puts them (measured b4 s4096 h16 d256: 1.075 -> 0.953 ms causal, 1.959 -> 1.734 full;
-// the same flag makes the dK/dV kernels of this file spill).
-hipError_t run_bwd_dq_256(const KParams &p, hipStream_t stream) {
-    return p.is_bf16 ? launch_dq<256, true, 4>(p, stream) : launch_dq<256, false, 4>(p, stream);
+#if defined(VFA_DQ_ILP_TU)
+// The one-block-per-workgroup dQ kernels from d = 128 up, a translation unit of their own
+// (bwd_dq_ilp.hip) because they are built under LLVM's ILP-first scheduler: the default one puts
+// every LDS read right in front of its MFMA, which nothing hides at one wave per SIMD (d > 128:
+// measured b4 s4096 h16 d256 1.075 -> 0.953 ms causal, 1.959 -> 1.734 full) and little does at two
+// (d = 128 with the persistent kernel switched off: b8 s4096 h32 causal 1.500 -> 1.443 ms, b32 s512
+// h16 0.104 -> 0.097).  At d = 64 the two schedulers tie (-3 ... +1.5 %), and the same flag makes the
+// dK/dV kernels of this file spill.
+hipError_t run_bwd_dq_ilp(const KParams &p, hipStream_t stream, bool waves8) {
+    const bool bf = p.is_bf16;
+    if (p.d > 128) return bf ? launch_dq<256, true, 4>(p, stream) : launch_dq<256, false, 4>(p, stream);
+    if (waves8) return bf ? launch_dq<128, true, 8>(p, stream) : launch_dq<128, false, 8>(p, stream);
+    return bf ? launch_dq<128, true, 4>(p, stream) : launch_dq<128, false, 4>(p, stream);
 }
 #elif !defined(VFA_DROPOUT_TU)
 hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
@@ -1834,7 +1839,7 @@ hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *ev)
 
 }  // namespace vfa
 
-#if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ256_TU)
+#if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ_ILP_TU)
 extern "C" __attribute__((visibility("default"))) int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_dkdv), n * sizeof(unsigned long long));
 }
