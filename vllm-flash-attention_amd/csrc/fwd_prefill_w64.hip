@@ -3,8 +3,8 @@
 // for the LDS bandwidth of a CU.
 //
 // In the 8-wave kernel every wave reads the whole 64-key K and V tile from LDS (32 KiB) for its 32
-// rows: 256 KiB per tile and CU, which at 128 bytes per cycle is exactly the 2048 cycles the
-// tile's MFMAs take on a SIMD -- the two limits coincide and every imperfect overlap is lost time.
+// rows: 256 KiB per tile and CU, half of what the LDS array can deliver in the 2048 cycles the
+// tile's MFMAs take on a SIMD.
 // Here a wave owns two 32-row halves and every K fragment and every transposed V fragment it reads
 // feeds two MFMAs: half the LDS traffic per MFMA.  With one wave per SIMD nothing but the wave's own
 // instruction stream hides its vector work, so the tile loop is software-pipelined by hand:
