@@ -14,6 +14,9 @@ for w in c3_fwd c2 c5 c4; do
   timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err
 done
 echo benches done
+timeout -k 10 300 python tools/perf_headdims.py 160 192 256 > $O/headdims.txt 2>&1
+timeout -k 10 600 python tools/seqlen_sweep.py $O/seqlen_sweep.json > $O/seqlen_sweep.log 2>&1
+echo sweeps done
 B="--steps 10 --warmup 3 --no-cpu-baseline --no-sdpa"
 for w in c3 c5 c2 c4; do
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -o $w -- python3 bench.py --workload $w $B > $O/trace_$w.log 2>&1
