@@ -218,6 +218,72 @@ def test_wide_head_dim_many_steps_grouped_heads_and_ragged_batch():
     _check_grads(g, ref, "fp16")
 
 
+WIDE_FWD = [
+    # dt, b, sq, sk, h, hk, d, causal, window     (several row blocks and many tiles per block)
+    ("bf16", 2, 1200, 1200, 4, 2, 256, True, (-1, -1)),
+    ("fp16", 1, 700, 1500, 2, 2, 256, True, (-1, -1)),      # sq < sk: the diagonal starts 800 keys in
+    ("bf16", 1, 1500, 600, 2, 1, 192, True, (-1, -1)),      # sq > sk: leading row blocks see no key
+    ("bf16", 1, 1000, 1000, 2, 2, 256, False, (300, 100)),  # window: the wave's tile range starts inside the block's
+    ("fp16", 3, 129, 67, 2, 2, 256, False, (-1, -1)),       # one row past a block edge, two tiles, key tail
+    ("bf16", 1, 1, 1000, 4, 4, 256, True, (-1, -1)),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_FWD, ids=[str(c) for c in WIDE_FWD])
+def test_hand_pipelined_forward_vs_oracle_and_general_kernel(case):
+    """fwd_prefill_wide.hip (what d > 128 takes without ALiBi) against the oracle and against the
+    general kernel (development library, switch 4 = 2): the two follow the running maximum with
+    different slack, so they agree up to the rounding of P and O, and exactly in which rows see no
+    key (LSE = +inf).  The output buffer is poisoned first: every row must be written."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import TDT, f32, ulp_tol
+    dt, b, sq, sk, h, hk, d, causal, window = case
+    torch.manual_seed(3 * sq + sk)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=TDT[dt])
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=TDT[dt])
+    kw = dict(causal=causal, window=window)
+    out, lse = cabi.fwd(q, k, v, out=torch.full_like(q, float("nan")), **kw)[:2]
+    assert not torch.isnan(out).any()
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), dtype=dt, **kw)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol(dt, ro)
+    got = lse.cpu().numpy()
+    inf = np.isposinf(rl)
+    assert (np.isposinf(got) == inf).all()
+    assert np.abs(got[~inf] - rl[~inf]).max(initial=0.0) <= 1e-3
+    with cabi.dev(4, 2):
+        o0, l0 = cabi.fwd(q, k, v, **kw)[:2]
+    assert np.abs(f32(out) - f32(o0)).max() <= 2 * ulp_tol(dt, ro)
+    assert (np.isposinf(l0.cpu().numpy()) == inf).all()
+
+
+def test_hand_pipelined_forward_kvcache_call_and_strided_inputs():
+    """The kv-cache entry point at d = 256 with 200 query tokens per sequence (prefill against a
+    cache: per-sequence key counts, a batch-index indirection into the cache, causal alignment at
+    the bottom right), and q / k / v as strided views of one packed tensor."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(9)
+    b, sq, cap, h, hk, d = 3, 200, 900, 4, 2, 256
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    kc = torch.randn(b + 2, cap, hk, d, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn_like(kc)
+    lens = torch.tensor([900, 333, 200], dtype=torch.int32, device="cuda")
+    idx = torch.tensor([4, 0, 2], dtype=torch.int32, device="cuda")
+    out, _ = cabi.fwd(q, kc, vc, causal=True, cache_seqlens=lens, cache_batch_idx=idx, kvcache=True)[:2]
+    ro, _ = fa_oracle.attention_fwd(f32(q), f32(kc[idx.long()]), f32(vc[idx.long()]), dtype="bf16", causal=True,
+                                    cache_seqlens=lens.cpu().numpy())
+    assert np.abs(f32(out) - ro).max() <= ulp_tol("bf16", ro)
+    qkv = torch.randn(2, 600, 3, 2, d, device="cuda", dtype=torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    out, lse = cabi.fwd(q, k, v, causal=True)[:2]
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), dtype="bf16", causal=True)
+    assert np.abs(f32(out) - ro).max() <= ulp_tol("bf16", ro)
+    assert np.abs(lse.cpu().numpy() - rl).max() <= 1e-3
+
+
 @pytest.mark.parametrize("paged", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
 def test_varlen_seqused_k(paged, causal):
