@@ -877,7 +877,7 @@ static bool paged_fits_direct(const KParams &p) {
            (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
 }
 
-#if !defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)
+#if (!defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)) || defined(VFA_FWD64_TU)
 template <int DP, bool BF16, int NW>
 static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     // contiguous K/V: straight into LDS where the lane map allows it (measured on MI355X against
@@ -895,7 +895,20 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     return launch_prefill_impl<DP, BF16, NW, 0>(p, stream);
 }
 
+#endif
+#if defined(VFA_FWD64_TU)
+// The d <= 64 instantiations, a translation unit of their own (fwd_prefill_d64.hip) because they are
+// built with -fno-slp-vectorize: hipcc packs pairs of the softmax's fp32 adds and multiplies into
+// v_pk_add_f32 / v_pk_mul_f32, which hold the vector issue port longer than the two instructions
+// they replace -- and at this head dim the vector instructions, not the MFMAs, bound the tile
+// (measured b4 s2048 h16 causal 589 -> 605 TFLOP/s, b8 s2048 h32 full 774 -> 808, b4 s4096 h32
+// causal 776 -> 806; the d = 128 kernels lose 5-11 % under the same flag).
+hipError_t run_fwd_prefill_64(const KParams &p, hipStream_t stream) {
+    return p.is_bf16 ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
+}
+#elif !defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
+hipError_t run_fwd_prefill_64(const KParams &p, hipStream_t stream);          // fwd_prefill_d64.hip
 bool fwd_prefill_w64_ok(const KParams &p);
 hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
@@ -915,7 +928,7 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
 #endif
     // the geometry: vfa_dispatch.h (work per CU first, keys per block second)
     const int geo = fwd_geometry(p, device_num_cus());
-    if (p.d <= 64) return bf ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
+    if (p.d <= 64) return run_fwd_prefill_64(p, stream);
     if (geo == VFA_GEO_WIDE32) return run_fwd_prefill_wide(p, stream);
     if (p.d > 128) return bf ? launch_prefill<256, true, 4>(p, stream) : launch_prefill<256, false, 4>(p, stream);
     // Persistent workgroups (fwd_prefill_persist.hip) wherever every CU gets at least two 256-row
