@@ -13,7 +13,8 @@ import bench
 SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 8192, 32, 8, 128, True),
           (4, 2048, 16, 16, 64, True), (32, 512, 16, 16, 128, True), (16, 1024, 16, 16, 128, False),
           (8, 2048, 32, 32, 64, False), (32, 512, 32, 32, 64, True), (4, 4096, 32, 32, 64, True),   # 7, 8
-          (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False), (16, 1024, 8, 8, 256, True)]   # 9, 10, 11
+          (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False), (16, 1024, 8, 8, 256, True),   # 9, 10, 11
+          (16, 2048, 64, 8, 128, False), (16, 2048, 64, 8, 128, True)]   # 12, 13: the shape of the programming guide's forward example
 
 
 def main():
