@@ -157,15 +157,22 @@ def _config1_checks(fa, F, torch, q, k, v, b, s, h, d):
 
 def test_decode_split_count_counts_packed_gqa_rows_like_the_launch():
     """Grouped heads, few query tokens: the planner's work items are (batch, KV head, 32-row block of
-    seqlen_q * group rows), the decode kernel's grid; MHA and long queries keep the reference's count."""
+    seqlen_q * group rows), the decode kernel's grid, while the packed rows fit one such block, and
+    the packed prefill kernel's 128-row blocks beyond; MHA and long queries keep the reference's count."""
     import cabi
     lib = cabi.lib()
     cus = 256
     for sq in (1, 4, 8, 9, 16, 33, 64):
         for h, hk in ((32, 8), (16, 2), (8, 1)):
             g = h // hk
-            mb = (sq * g + 31) // 32
-            want = min((8192 + 127) // 128, lib.vfa_num_splits_heuristic(2 * hk * mb, 2 * cus, (8192 + 127) // 128, 128))
+            if sq * g > 32:
+                # more than one decode block: the packed prefill kernel, 128-row blocks per KV head,
+                # at least four 64-key tiles per split, nothing split once a quarter of the slots is filled
+                blocks = 2 * hk * ((sq * g + 127) // 128)
+                want = 1 if blocks * 4 > 2 * cus else lib.vfa_num_splits_heuristic(blocks, 2 * cus, (8192 // 64) // 4, 128)
+            else:
+                mb = (sq * g + 31) // 32
+                want = min((8192 + 127) // 128, lib.vfa_num_splits_heuristic(2 * hk * mb, 2 * cus, (8192 + 127) // 128, 128))
             assert lib.vfa_decode_num_splits(2, h, hk, 128, 8192, sq, cus) == want, (sq, h, hk)
     assert lib.vfa_decode_num_splits(2, 8, 8, 128, 8192, 1, cus) == lib.vfa_splitkv_num_splits(2, 8, 128, 8192, 1, cus)
     assert lib.vfa_decode_num_splits(2, 32, 8, 128, 8192, 200, cus) == lib.vfa_splitkv_num_splits(2, 32, 128, 8192, 200, cus)

@@ -21,6 +21,8 @@ hipError_t run_append_kv(const KParams &p, hipStream_t stream);
 hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
 hipError_t run_fwd_prefill_dropout(const KParams &p, hipStream_t stream);
 hipError_t run_fwd_prefill_split(const KParams &p, hipStream_t stream);
+bool fwd_prefill_pack_ok(const KParams &p);                                  // fwd_prefill_pack.hip
+hipError_t run_fwd_prefill_pack(const KParams &p, hipStream_t stream);
 bool fwd_prefill_split_ok(const KParams &p);
 hipError_t run_fwd_combine(const KParams &p, hipStream_t stream);
 hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *stage_events);
@@ -192,9 +194,27 @@ extern "C" int vfa_splitkv_num_splits(int batch, int num_heads, int head_size, i
     return std::min(tiles, vfa_num_splits_heuristic(batch * num_heads * num_m_blocks, num_cus_ * 2, num_n_blocks, 128));
 }
 
+// Grouped query heads with a few query positions per sequence -- more rows than one 32-row decode
+// block holds, fewer positions than fill a 128-row prefill block per head: the prefill kernel with
+// the group packed into the rows of its KV head (fwd_prefill_pack.hip) sweeps the keys once per KV
+// head.  Measured (b64 kv4096 h32/8 d128 fp16, query positions 16 / 32 / 64): 260 / 456 / 597 us with
+// 32-row decode blocks or one 128-row block per query head; see DESIGN.md for the packed figures.
+static bool pack_rows_shape(int ratio, int seqlen_q) {
+    if (vfa::g_tuning[2] & 4) return false;   // development switch 2, bit 2: never
+    return ratio > 1 && seqlen_q * ratio > 32 && seqlen_q < 128;
+}
+
 extern "C" int vfa_decode_num_splits(int batch, int num_heads, int num_heads_k, int head_size, int max_seqlen_k,
                                      int max_seqlen_q, int num_cus_) {
     const int ratio = (num_heads_k > 0 && num_heads % num_heads_k == 0) ? num_heads / num_heads_k : 1;
+    if (pack_rows_shape(ratio, max_seqlen_q) && head_size <= 128) {
+        // work items: 128-row blocks of packed rows per (batch, KV head); the rule of the prefill
+        // kernel's split variants (vfa_splitkv_num_splits above)
+        const int blocks = batch * num_heads_k * ((max_seqlen_q * ratio + 127) / 128);
+        const int chunks = ((max_seqlen_k + 63) / 64) / 4;   // at least 4 tiles (256 keys) per split
+        if (blocks * 4 > num_cus_ * 2 || chunks < 2) return 1;
+        return vfa_num_splits_heuristic(blocks, num_cus_ * 2, chunks, 128);
+    }
     if (ratio <= 1 || max_seqlen_q > 64)
         return vfa_splitkv_num_splits(batch, num_heads, head_size, max_seqlen_k, max_seqlen_q, num_cus_);
     // run_fwd_splitkv / launch_decode_hpb: rows = seqlen_q * ratio in 32-row blocks, one (pair of)
@@ -240,7 +260,10 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
         // prefill kernel's split variants (128-row blocks), when they can load this K/V layout
         // (they do not rotate the query: rotary tables keep the decode kernel).
         const bool q_rotary = k.knew && k.rotary_dim > 0;
-        if (k.seqlen_q > 64 && !q_rotary && vfa::fwd_prefill_split_ok(k)) {
+        if (pack_rows_shape(k.h_ratio, k.seqlen_q) && !q_rotary && vfa::fwd_prefill_pack_ok(k)) {
+            e = vfa::run_fwd_prefill_pack(k, stream);
+            if (e == hipSuccess) e = vfa::run_fwd_combine(k, stream);
+        } else if (k.seqlen_q > 64 && !q_rotary && vfa::fwd_prefill_split_ok(k)) {
             e = vfa::run_fwd_prefill_split(k, stream);
             if (e == hipSuccess) e = vfa::run_fwd_combine(k, stream);
         } else {
@@ -249,9 +272,23 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
         if (e != hipSuccess) return hip_fail(e, "splitkv launch");
         return VFA_OK;
     }
+    // A few query positions of grouped heads: the group packed into the rows of its KV head (the
+    // prefill kernel does not rotate the query: rotary tables keep the decode kernel).
+    if (pack_rows_shape(k.h_ratio, k.seqlen_q) && !(k.knew && k.rotary_dim > 0) && vfa::fwd_prefill_pack_ok(k)) {
+        e = vfa::run_fwd_prefill_pack(k, stream);
+        if (e != hipSuccess) return hip_fail(e, "prefill (packed heads) launch");
+        return VFA_OK;
+    }
     // Small query blocks against long keys (decode): the split kernel's tiling (few query rows,
-    // many waves along the keys) is the right one even with a single split.
-    if (force_split || k.seqlen_q <= 32) {
+    // many waves along the keys) is the right one even with a single split.  The reference sends
+    // every call that appends, pages or indexes the cache to its split kernel (flash_api.cpp:919)
+    // because only that kernel can; here the prefill kernels read paged and indexed caches too and
+    // the new keys are in the cache before the attention kernel starts, so only a query that is
+    // still to be rotated (the decode kernel does that on the fly) keeps long query blocks there
+    // (measured b64 kv4096 h32/8 d128 paged, 64 query positions: 1049 us in 32-row decode blocks).
+    const bool q_rotary = k.knew && k.rotary_dim > 0;
+    (void)force_split;
+    if (q_rotary || k.seqlen_q <= 32) {
         e = vfa::run_fwd_splitkv(k, stream);
         if (e != hipSuccess) return hip_fail(e, "decode launch");
         return VFA_OK;

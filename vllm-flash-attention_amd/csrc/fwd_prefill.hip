@@ -131,9 +131,17 @@ struct PrefillCfg {
 // part writes its normalised fp32 O and its LSE (-inf if it saw no key, :513-552) to p.oaccum /
 // p.lseaccum and fwd_combine_kernel merges them.  For launches whose (batch, head, row-block)
 // count alone would leave most CUs idle: a few hundred query rows against a long context.
-template <int DP, bool BF16, int NW, int LD, bool DROP, bool SPLIT = false>
+//
+// PACK: the query heads that share a KV head are packed into the rows of one workgroup (row i of a
+// (batch, KV head) pair = query position i / ratio, head i % ratio of the group; ratio =
+// p.pack_gqa, and the launcher hands over p.h = p.h_k, p.h_ratio = 1, so the grid walks the KV
+// heads).  For a few query tokens per sequence against a long cache (chunked prefill, draft-token
+// verification): 16 tokens of 4 grouped heads fill half a 128-row block and sweep the keys once,
+// where one block per query head sweeps them four times at an eighth of the rows each.
+template <int DP, bool BF16, int NW, int LD, bool DROP, bool SPLIT = false, bool PACK = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
+    static_assert(!PACK || (NW == 4 && !DROP), "packed grouped heads: 4-wave geometry, no dropout");
     constexpr bool DIRECT = LD == 3;                 // contiguous K/V, loaded straight into LDS
     constexpr bool PDIRECT = LD == 4;                // paged K/V (per-page descriptors), loaded straight into LDS
     constexpr bool TO_LDS = DIRECT || PDIRECT;
@@ -152,10 +160,12 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
     int bidb, bidh, m_block;
     map_block(p, n_mblocks, 32 * ((NW == 8 || DP == 256) ? 1 : 2), bidb, bidh, m_block);
-    const int hk = bidh / p.h_ratio;
+    const int hk = bidh / p.h_ratio;   // (PACK: p.h_ratio is 1 and bidh is the KV head)
+    const int ratio = PACK ? p.pack_gqa : 1;
 
     const BlockInfo bi(p, bidb);
     const int sq = bi.sq, sk = bi.sk;
+    const int sq_rows = sq * ratio;    // rows of this (batch, head): query positions (x grouped heads)
     // Philox state: the caller's values, or (under graph capture) read on the device at replay
     // time from the generator's captured state (at::cuda::philox::unpack, flash_fwd_kernel.h:45)
     unsigned long long ph_seed = p.philox_seed, ph_offset = p.philox_offset;
@@ -169,31 +179,53 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
             p.rng_state[1] = ph_offset;
         }
     }
-    if (m_block * BM >= sq) return;
+    if (m_block * BM >= sq_rows) return;
     const unsigned long long drop_off = ph_offset + (unsigned long long)((bidb * p.h + bidh) * 32);  // dropout.h:21
 
     // ---- key tile range: flash_fwd_kernel.h:59-67 ----
-    int n_min = !p.is_local ? 0 : max(0, (m_block * BM + sk - sq - p.wl) / BN);
+    // query positions [pos_lo_b, pos_hi_b) of the block
+    const int pos_lo_b = PACK ? (m_block * BM) / ratio : m_block * BM;
+    const int pos_hi_b = PACK ? min(sq, ((m_block + 1) * BM - 1) / ratio + 1) : (m_block + 1) * BM;
+    int n_min = !p.is_local ? 0 : max(0, (pos_lo_b + sk - sq - p.wl) / BN);
     int n_max = (sk + BN - 1) / BN;
     if (p.is_causal || p.is_local)
-        n_max = min(n_max, ((m_block + 1) * BM + sk - sq + p.wr + BN - 1) / BN);
+        n_max = min(n_max, (pos_hi_b + sk - sq + p.wr + BN - 1) / BN);
 
+    // Row -> memory.  Unpacked: row = query position, one head.  PACK: (position, head) per row;
+    // qg / og / lse_g then point at head 0 of the KV head's group and the head is part of the row offset.
+    const int h_all = p.h * ratio;     // query heads of the tensors
+    const int head0 = bidh * ratio;
     const unsigned short *qg = (const unsigned short *)p.q + bi.q_off(p.q_bs, p.q_rs, bidb) +
-                               (int64_t)bidh * p.q_hs;
+                               (int64_t)head0 * p.q_hs;
     unsigned short *og = (unsigned short *)p.o + bi.q_off(p.o_bs, p.o_rs, bidb) +
-                         (int64_t)bidh * p.o_hs;
-    float *lse_g = p.lse + ((int64_t)bidb * p.h + bidh) * p.seqlen_q;
+                         (int64_t)head0 * p.o_hs;
+    float *lse_g = p.lse + ((int64_t)bidb * h_all + head0) * p.seqlen_q;
     float *oacc_g = nullptr;
     if constexpr (SPLIT) {
         const int split = blockIdx.y;
         const int per = (((p.seqlen_k + BN - 1) / BN) + p.num_splits - 1) / p.num_splits;  // from the capacity
         n_min = max(n_min, split * per);
         n_max = min(n_max, (split + 1) * per);
-        const int64_t acc_row0 = (((int64_t)split * p.b + bidb) * p.h + bidh) * p.seqlen_q;
+        const int64_t acc_row0 = (((int64_t)split * p.b + bidb) * h_all + head0) * p.seqlen_q;
         lse_g = p.lseaccum + acc_row0;
         oacc_g = p.oaccum + acc_row0 * p.d;
     }
-    const int q0w = m_block * BM + wave * 32;  // first query row of this wave
+    const int q0w = m_block * BM + wave * 32;  // first row of this wave
+    // (position, head of the group) of row `row` of this (batch, head)
+    auto row_pos = [&](const int row) __attribute__((always_inline)) -> int { return PACK ? row / ratio : row; };
+    auto row_head = [&](const int row) __attribute__((always_inline)) -> int { return PACK ? row % ratio : 0; };
+    // element offsets of a row in Q / O, in the LSE plane and in the split partials
+    auto q_row_off = [&](const int row) __attribute__((always_inline)) -> int64_t {
+        return (int64_t)row_pos(row) * p.q_rs + (PACK ? (int64_t)row_head(row) * p.q_hs : 0);
+    };
+    auto o_row_off = [&](const int row) __attribute__((always_inline)) -> int64_t {
+        return (int64_t)row_pos(row) * p.o_rs + (PACK ? (int64_t)row_head(row) * p.o_hs : 0);
+    };
+    auto stat_off = [&](const int row) __attribute__((always_inline)) -> int64_t {   // lse_g[...], oacc_g[... * d]
+        return PACK ? (int64_t)row_head(row) * p.seqlen_q + row_pos(row) : (int64_t)row;
+    };
+    const int pos_l = row_pos(q0w + r);                                   // this lane's query position
+    const int pos_lo_w = row_pos(q0w), pos_hi_w = PACK ? (q0w + 31) / ratio + 1 : q0w + 32;   // the wave's, [lo, hi)
     FWD_BLK_STAMP(4);
 
     if (n_max <= n_min) {
@@ -201,17 +233,17 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         // a split that sees none: partial O = 0, LSE = -inf (:513-552).
         for (int c = tid; c < BM * CPR; c += NT) {
             const int row = m_block * BM + c / CPR, ch = c % CPR;
-            if (row < sq && ch * 8 < p.d) {
+            if (row < sq_rows && ch * 8 < p.d) {
                 if constexpr (SPLIT) {
-                    *(f32x4 *)(oacc_g + (int64_t)row * p.d + ch * 8) = f32x4{0, 0, 0, 0};
-                    *(f32x4 *)(oacc_g + (int64_t)row * p.d + ch * 8 + 4) = f32x4{0, 0, 0, 0};
+                    *(f32x4 *)(oacc_g + stat_off(row) * p.d + ch * 8) = f32x4{0, 0, 0, 0};
+                    *(f32x4 *)(oacc_g + stat_off(row) * p.d + ch * 8 + 4) = f32x4{0, 0, 0, 0};
                 } else {
-                    *(i32x4 *)(og + (int64_t)row * p.o_rs + ch * 8) = i32x4{0, 0, 0, 0};
+                    *(i32x4 *)(og + o_row_off(row) + ch * 8) = i32x4{0, 0, 0, 0};
                 }
             }
         }
         for (int c = tid; c < BM; c += NT)
-            if (m_block * BM + c < sq) lse_g[m_block * BM + c] = SPLIT ? -INFINITY : INFINITY;
+            if (m_block * BM + c < sq_rows) lse_g[stat_off(m_block * BM + c)] = SPLIT ? -INFINITY : INFINITY;
         return;
     }
 
@@ -467,8 +499,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
         const int row = q0w + r;
-        const bool rok = row < sq;
-        const unsigned short *qr = qg + (int64_t)(rok ? row : 0) * p.q_rs;
+        const bool rok = row < sq_rows;
+        const unsigned short *qr = qg + (rok ? q_row_off(row) : 0);
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const int col = 16 * s + 8 * hh;
@@ -556,8 +588,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         // The tile range [n_min, n_max) is the block's; a wave whose 32 rows see none of this
         // tile's keys (above its own diagonal, or left of its window) only helps with the staging.
         bool skip = false;
-        if (p.is_causal || p.is_local) skip = c0 >= q0w + 32 + sk - sq + p.wr;
-        if (p.is_local) skip = skip || (c0 + BN <= q0w + sk - sq - p.wl);
+        if (p.is_causal || p.is_local) skip = c0 >= pos_hi_w + sk - sq + p.wr;
+        if (p.is_local) skip = skip || (c0 + BN <= pos_lo_w + sk - sq - p.wl);
         if (!skip) {
 
         // ---- S^T = K Q^T : s[kb2][reg] = score(key = n*64 + 32 kb2 + (reg&3) + 8 (reg>>2) + 4 hh,
@@ -568,8 +600,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         // current reference point, go with the MFMAs of the second 32 keys.  They stand unless the
         // tile needs a mask or moves the reference point (both rare), which redoes them.
         bool need_mask = c0 + BN > sk;
-        if (p.is_causal || p.is_local) need_mask = need_mask || (c0 + BN > q0w + 1 + sk - sq + p.wr);
-        if (p.is_local) need_mask = need_mask || (c0 < q0w + 31 + sk - sq - p.wl);
+        if (p.is_causal || p.is_local) need_mask = need_mask || (c0 + BN > pos_lo_w + 1 + sk - sq + p.wr);
+        if (p.is_local) need_mask = need_mask || (c0 < pos_hi_w - 1 + sk - sq - p.wl);
         const bool need = need_mask || has_alibi;
         f32x16 s[2];
         i32x4 pf[4];
@@ -633,7 +665,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         if (need && !has_alibi && !p.is_local) {
             // causal diagonal and / or key tail only: key offset of register j (a constant) against
             // one per-lane limit -- a compare and a select per score
-            const int hi = p.is_causal ? min(sk, q0w + r + 1 + sk - sq) : sk;
+            const int hi = p.is_causal ? min(sk, pos_l + 1 + sk - sq) : sk;
             const int lim = hi - c0 - 4 * hh;
 #pragma unroll
             for (int kb2 = 0; kb2 < 2; kb2++)
@@ -659,7 +691,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                 for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
             }
         } else if (need) {
-            const int row = q0w + r;
+            const int row = pos_l;
             const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
             const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
 #pragma unroll
@@ -794,13 +826,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         const float slope = alibi * p.scale;
         lse += p.is_causal ? slope * (float)cref : -slope * (float)(q0w + r + sk - sq - cref);
     }
-    if (hh == 0 && q0w + r < sq) lse_g[q0w + r] = lse;
+    if (hh == 0 && q0w + r < sq_rows) lse_g[stat_off(q0w + r)] = lse;
 
     if constexpr (SPLIT) {
         // fp32 partial result straight from the accumulators: lane (r, hh) holds, per d block and
         // group g4, four consecutive columns of row q0w + r
-        if (q0w + r < sq) {
-            float *dst = oacc_g + (int64_t)(q0w + r) * p.d;
+        if (q0w + r < sq_rows) {
+            float *dst = oacc_g + stat_off(q0w + r) * p.d;
 #pragma unroll
             for (int db = 0; db < NDB; db++)
 #pragma unroll
@@ -831,19 +863,19 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         const int c = lane + 64 * i;
         const int row = c / CPR, ch = c % CPR;
         const i32x4 w = *(const i32x4 *)(ob + row * Cfg::O_ROWB + ch * 16);
-        if (q0w + row < sq && ch * 8 < p.d)
-            *(i32x4 *)(og + (int64_t)(q0w + row) * p.o_rs + ch * 8) = w;
+        if (q0w + row < sq_rows && ch * 8 < p.d)
+            *(i32x4 *)(og + o_row_off(q0w + row) + ch * 8) = w;
     }
     FWD_BLK_STAMP(3);
 }
 
-template <int DP, bool BF16, int NW, int LD, bool DROP = false, bool SPLIT = false>
+template <int DP, bool BF16, int NW, int LD, bool DROP = false, bool SPLIT = false, bool PACK = false>
 static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
-    const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
-    const long long blocks = (long long)n_mblocks * p.b * p.h;
+    const int n_mblocks = (p.seqlen_q * (PACK ? p.pack_gqa : 1) + Cfg::BM - 1) / Cfg::BM;
+    const long long blocks = (long long)n_mblocks * p.b * p.h;   // (PACK: p.h is the KV head count)
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP, SPLIT>;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP, SPLIT, PACK>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SPLIT ? (unsigned)p.num_splits : 1u), dim3(Cfg::NT),
@@ -896,7 +928,33 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 }
 
 #endif
-#if defined(VFA_FWD64_TU)
+#if defined(VFA_PACK_TU)
+// Grouped query heads packed into the rows of their KV head (template parameter PACK), a translation
+// unit of its own (fwd_prefill_pack.hip).  For 64 < d <= 128 and d <= 64, contiguous K/V or pages of
+// a power of two; with or without a split of the keys.
+bool fwd_prefill_pack_ok(const KParams &p) {
+    if (p.h_ratio <= 1 || p.alibi_slopes || p.d > 128) return false;
+    return kv_fits_buffer(p) || (p.d <= 64 ? paged_fits_direct<64>(p) : paged_fits_direct<128>(p));
+}
+template <int DP, bool BF16, bool SPLIT>
+static hipError_t launch_pack(const KParams &p, hipStream_t stream) {
+    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, 3, false, SPLIT, true>(p, stream)
+                             : launch_prefill_impl<DP, BF16, 4, 4, false, SPLIT, true>(p, stream);
+}
+template <int DP, bool BF16>
+static hipError_t launch_pack_s(const KParams &p, hipStream_t stream) {
+    return p.num_splits > 1 ? launch_pack<DP, BF16, true>(p, stream) : launch_pack<DP, BF16, false>(p, stream);
+}
+hipError_t run_fwd_prefill_pack(const KParams &p_in, hipStream_t stream) {
+    KParams p = p_in;
+    p.pack_gqa = p_in.h_ratio;   // the grid walks the KV heads
+    p.h = p_in.h_k;
+    p.h_ratio = 1;
+    const bool bf = p.is_bf16;
+    if (p.d <= 64) return bf ? launch_pack_s<64, true>(p, stream) : launch_pack_s<64, false>(p, stream);
+    return bf ? launch_pack_s<128, true>(p, stream) : launch_pack_s<128, false>(p, stream);
+}
+#elif defined(VFA_FWD64_TU)
 // The d <= 64 instantiations, a translation unit of their own (fwd_prefill_d64.hip) because they are
 // built with -fno-slp-vectorize: hipcc packs pairs of the softmax's fp32 adds and multiplies into
 // v_pk_add_f32 / v_pk_mul_f32, which hold the vector issue port longer than the two instructions

@@ -67,7 +67,8 @@ struct KParams {
     int64_t o_bs, o_rs, o_hs;
     int b, h, h_k, h_ratio, d;
     int dbg_flags;
-    int pack_gqa;               // decode kernel only: rows = (query position, query head of the KV group)
+    int pack_gqa;               // rows = (query position, query head of the KV group): decode kernel (a flag),
+                                // packed prefill kernel (the group size; p.h = p.h_k, p.h_ratio = 1 there)
     int seqlen_q, seqlen_k;     // max query length, max key length / cache capacity
     const int *cu_seqlens_q;    // b+1 or null
     const int *cu_seqlens_k;    // b+1 cumulative, or b lengths when !k_cumulative, or null
