@@ -46,7 +46,7 @@ class VfaParams(C.Structure):
         ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64), ("rng_state", _p),
         ("philox_seed_ptr", _p), ("philox_offset_ptr", _p), ("philox_offset_intragraph", C.c_uint32),
         ("s_dmask", _p), ("seqlen_q_rounded", _int), ("seqlen_k_rounded", _int),
-        ("bwd_head_splits", _int), ("bwd_part_rows", _i64), ("seqlen_ro", _int),
+        ("bwd_head_splits", _int), ("bwd_part_rows", _i64), ("seqlen_ro", _int), ("total_q", _int),
     ]
 
 
@@ -191,6 +191,7 @@ def fwd(q, k, v, *, softmax_scale=None, causal=False, window=(-1, -1), alibi_slo
     P.is_seqlens_k_cumulative = 1
     if varlen:
         P.cu_seqlens_q, P.cu_seqlens_k = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr()
+        P.total_q = q.shape[0]
     if cache_seqlens is not None:
         P.cu_seqlens_k = cache_seqlens.data_ptr()
         P.is_seqlens_k_cumulative = 0

@@ -274,7 +274,13 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
     }
     // A few query positions of grouped heads: the group packed into the rows of its KV head (the
     // prefill kernel does not rotate the query: rotary tables keep the decode kernel).
-    if (pack_rows_shape(k.h_ratio, k.seqlen_q) && !(k.knew && k.rotary_dim > 0) && vfa::fwd_prefill_pack_ok(k)) {
+    // ... and ragged batches whose sequences are short on average (decode sequences and short chunks
+    // batched with a few long ones): a sequence of one query position then costs one workgroup per KV
+    // head instead of one per query head, and the long ones lose nothing but the 8-wave geometry.
+    const bool short_ragged = k.h_ratio > 1 && !(vfa::g_tuning[2] & 4) && p->cu_seqlens_q && p->total_q > 0 &&
+                              k.seqlen_q >= 128 && (long long)p->total_q < 128LL * k.b;
+    if ((pack_rows_shape(k.h_ratio, k.seqlen_q) || short_ragged) && !(k.knew && k.rotary_dim > 0) &&
+        vfa::fwd_prefill_pack_ok(k)) {
         e = vfa::run_fwd_prefill_pack(k, stream);
         if (e != hipSuccess) return hip_fail(e, "prefill (packed heads) launch");
         return VFA_OK;

@@ -590,6 +590,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
         bool skip = false;
         if (p.is_causal || p.is_local) skip = c0 >= pos_hi_w + sk - sq + p.wr;
         if (p.is_local) skip = skip || (c0 + BN <= pos_lo_w + sk - sq - p.wl);
+        if constexpr (PACK) skip = skip || q0w >= sq_rows;   // a wave past the last row (short sequences of a ragged batch)
         if (!skip) {
 
         // ---- S^T = K Q^T : s[kb2][reg] = score(key = n*64 + 32 kb2 + (reg&3) + 8 (reg>>2) + 4 hh,

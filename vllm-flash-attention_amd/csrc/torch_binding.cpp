@@ -432,6 +432,7 @@ std::vector<Tensor> varlen_fwd(Tensor &q, const Tensor &k, const Tensor &v, OptT
     set_qkvo(P, qp, kp, vp, out, false);
     P.softmax_lse = lse.data_ptr<float>();
     P.b = b; P.seqlen_q = max_seqlen_q; P.seqlen_k = max_seqlen_k; P.h = h; P.h_k = hk; P.d = d;
+    P.total_q = (int)total_q;
     P.cu_seqlens_k = cu_seqlens_k.data_ptr<int32_t>();
     P.is_seqlens_k_cumulative = 1;
     if (seqused_k.has_value()) P.seqused_k = seqused_k.value().data_ptr<int32_t>();
