@@ -140,3 +140,52 @@ def test_python_api_takes_the_planner_and_the_packed_kernel():
     out = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True)
     ro, _ = fa_oracle.attention_fwd(_f(q), _f(kc), _f(vc), dtype="bf16", causal=True, cache_seqlens=lens.cpu().numpy())
     assert np.abs(_f(out) - ro).max() <= ulp_tol("bf16", ro)
+
+
+@pytest.mark.parametrize("paged", [False, True])
+def test_mixed_serving_batch_short_on_average(paged):
+    """One ragged call with many one-position sequences and a few long chunks (what a serving engine
+    batches): fewer than 128 query rows per sequence on average, so the grouped heads are packed
+    (the total_q hint of vfa_params), also for the sequences of several 128-row blocks."""
+    import cabi
+    from oracle import fa_oracle
+    from gpu_util import ulp_tol
+    torch.manual_seed(12 + paged)
+    ql = [1] * 9 + [300, 1, 130, 2, 1]
+    kl = [500, 33, 1000, 64, 65, 700, 16, 129, 400] + [300, 900, 500, 77, 1]
+    h, hk, d, page = 8, 2, 128, 16
+    cu = lambda l: torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device="cuda")
+    cq, ck = cu(ql), cu(kl)
+    q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    assert sum(ql) < 128 * len(ql) and max(ql) >= 128
+    kw = dict(causal=True, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+    ro, rl = fa_oracle.attention_fwd(_f(q), _f(k), _f(v), dtype="bf16", causal=True, cu_seqlens_q=cq.cpu().numpy(),
+                                     cu_seqlens_k=ck.cpu().numpy(), max_seqlen_q=max(ql), max_seqlen_k=max(kl))
+    if paged:
+        b = len(kl)
+        maxblk = (max(kl) + page - 1) // page
+        nblk = sum((n + page - 1) // page for n in kl) + 2
+        kp = torch.full((nblk, page, hk, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+        vp = torch.full_like(kp, float("nan"))
+        bt = torch.full((b, maxblk), 2 ** 30, dtype=torch.int32, device="cuda")
+        perm = torch.randperm(nblk, device="cuda")
+        o = 0
+        for i, n in enumerate(kl):
+            for j in range((n + page - 1) // page):
+                rows = min(page, n - j * page)
+                pg = int(perm[o]); o += 1
+                kp[pg, :rows] = k[int(ck[i]) + j * page: int(ck[i]) + j * page + rows]
+                vp[pg, :rows] = v[int(ck[i]) + j * page: int(ck[i]) + j * page + rows]
+                bt[i, j] = pg
+        out, lse = cabi.fwd(q, kp, vp, block_table=bt, **kw)[:2]
+    else:
+        out, lse = cabi.fwd(q, k, v, **kw)[:2]
+    assert not torch.isnan(out).any()
+    assert np.abs(_f(out) - ro).max() <= ulp_tol("bf16", ro)
+    for i, n in enumerate(ql):
+        assert np.abs(lse.cpu().numpy()[i, :, :n] - rl[i, :, :n]).max() <= 1e-3
+    with cabi.dev(2, 4):   # one block per query head
+        o0 = (cabi.fwd(q, kp, vp, block_table=bt, **kw) if paged else cabi.fwd(q, k, v, **kw))[0]
+    assert np.abs(_f(out) - _f(o0)).max() <= 2 * ulp_tol("bf16", ro)
