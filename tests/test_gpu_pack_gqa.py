@@ -33,6 +33,8 @@ DENSE = [
     ("bf16", 2, 40, 900, 8, 2, 128, False, (200, 50)),    # window on both sides
     ("bf16", 1, 50, 20, 8, 2, 128, True, (-1, -1)),       # more positions than keys: the first ones see nothing
     ("fp16", 2, 9, 129, 16, 2, 128, True, (64, 0)),       # 72 rows, causal window
+    ("bf16", 2, 24, 800, 8, 2, 256, True, (-1, -1)),      # d = 256
+    ("fp16", 1, 70, 333, 4, 1, 192, False, (-1, -1)),     # d = 192 on the 256-column kernel, three blocks
 ]
 
 

@@ -207,7 +207,7 @@ static bool pack_rows_shape(int ratio, int seqlen_q) {
 extern "C" int vfa_decode_num_splits(int batch, int num_heads, int num_heads_k, int head_size, int max_seqlen_k,
                                      int max_seqlen_q, int num_cus_) {
     const int ratio = (num_heads_k > 0 && num_heads % num_heads_k == 0) ? num_heads / num_heads_k : 1;
-    if (pack_rows_shape(ratio, max_seqlen_q) && head_size <= 128) {
+    if (pack_rows_shape(ratio, max_seqlen_q)) {
         // work items: 128-row blocks of packed rows per (batch, KV head); the rule of the prefill
         // kernel's split variants (vfa_splitkv_num_splits above)
         const int blocks = batch * num_heads_k * ((max_seqlen_q * ratio + 127) / 128);

@@ -931,11 +931,11 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 #endif
 #if defined(VFA_PACK_TU)
 // Grouped query heads packed into the rows of their KV head (template parameter PACK), a translation
-// unit of its own (fwd_prefill_pack.hip).  For 64 < d <= 128 and d <= 64, contiguous K/V or pages of
-// a power of two; with or without a split of the keys.
+// unit of its own (fwd_prefill_pack.hip).  Every head dim, contiguous K/V or pages of a power of two;
+// with or without a split of the keys.
 bool fwd_prefill_pack_ok(const KParams &p) {
-    if (p.h_ratio <= 1 || p.alibi_slopes || p.d > 128) return false;
-    return kv_fits_buffer(p) || (p.d <= 64 ? paged_fits_direct<64>(p) : paged_fits_direct<128>(p));
+    if (p.h_ratio <= 1 || p.alibi_slopes) return false;
+    return kv_fits_buffer(p) || paged_fits_direct<128>(p);   // (the page test does not depend on the head dim)
 }
 template <int DP, bool BF16, bool SPLIT>
 static hipError_t launch_pack(const KParams &p, hipStream_t stream) {
@@ -953,7 +953,8 @@ hipError_t run_fwd_prefill_pack(const KParams &p_in, hipStream_t stream) {
     p.h_ratio = 1;
     const bool bf = p.is_bf16;
     if (p.d <= 64) return bf ? launch_pack_s<64, true>(p, stream) : launch_pack_s<64, false>(p, stream);
-    return bf ? launch_pack_s<128, true>(p, stream) : launch_pack_s<128, false>(p, stream);
+    if (p.d <= 128) return bf ? launch_pack_s<128, true>(p, stream) : launch_pack_s<128, false>(p, stream);
+    return bf ? launch_pack_s<256, true>(p, stream) : launch_pack_s<256, false>(p, stream);
 }
 #elif defined(VFA_FWD64_TU)
 // The d <= 64 instantiations, a translation unit of their own (fwd_prefill_d64.hip) because they are
