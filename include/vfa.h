@@ -139,7 +139,7 @@ typedef struct vfa_params {
      * its end.  0 = unknown: no clamp and no check (the reference kernel's behaviour). */
     int seqlen_ro;
     /* Ragged forward: the rows of q (the reference's total_q, flash_api.cpp:475).  A hint for the
-     * dispatch -- with grouped heads and fewer than 128 rows per sequence on average (decode
+     * dispatch -- with grouped heads and fewer than 512 rows per sequence on average (decode
      * sequences and short chunks batched with a few long ones, as a serving engine batches them) the
      * query heads of a KV head are packed into the rows of one workgroup.  0 = unknown. */
     int total_q;

@@ -240,7 +240,13 @@ def _paged_prefill_equals_contiguous(varlen_func, d, page, sq, causal):
     ref = varlen_func(q, k, v, cq, ck, max(ql), max(kl), causal=causal)
     out = varlen_func(q, kc, vc, cq, ck, max(ql), max(kl), causal=causal, block_table=bt.cuda())
     assert not torch.isnan(out).any()
-    assert torch.equal(out, ref)   # (d > 128: both through fwd_prefill_wide.hip, pages of 16 / 64 / 128 rows)
+    if page & (page - 1) == 0:
+        assert torch.equal(out, ref)   # (d > 128: both through fwd_prefill_wide.hip, pages of 16 / 64 / 128 rows)
+    else:
+        # pages that are not a power of two take per-row addressing in the general kernel, while the
+        # contiguous call of this short ragged batch packs its grouped heads into rows: two
+        # instantiations, equal up to the rounding of P and O
+        assert (out.float() - ref.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.float().abs().max().item())
 
 
 @pytest.mark.parametrize("interleaved", [True, False])
@@ -496,7 +502,7 @@ def test_config4_varlen_gqa_window_alibi():
         alone, lse1 = _cabi().fwd(q[a:e], k[a:e], v[a:e], cu_seqlens_q=_cu([lens[i]]), cu_seqlens_k=_cu([lens[i]]),
                                   max_seqlen_q=mx, max_seqlen_k=mx, causal=True, window=(1024, 0),
                                   alibi_slopes=slopes[i:i + 1].contiguous())
-        assert torch.equal(alone, out[a:e])
+        assert torch.equal(alone, out[a:e])   # (both calls pack the grouped heads into rows: a windowed ragged batch)
     # one query head of the two longest sequences (true sliding window: 1024 < seqlen)
     for i, hq in ((0, 5), (1, 30)):
         a, e = cuh[i], cuh[i + 1]

@@ -275,10 +275,16 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
     // A few query positions of grouped heads: the group packed into the rows of its KV head (the
     // prefill kernel does not rotate the query: rotary tables keep the decode kernel).
     // ... and ragged batches whose sequences are short on average (decode sequences and short chunks
-    // batched with a few long ones): a sequence of one query position then costs one workgroup per KV
-    // head instead of one per query head, and the long ones lose nothing but the 8-wave geometry.
-    const bool short_ragged = k.h_ratio > 1 && !(vfa::g_tuning[2] & 4) && p->cu_seqlens_q && p->total_q > 0 &&
-                              k.seqlen_q >= 128 && (long long)p->total_q < 128LL * k.b;
+    // batched with a few long ones: a sequence of one query position then costs one workgroup per KV
+    // head instead of one per query head) or that attend through a sliding window (a packed block
+    // spans a quarter of the positions, so fewer of its tiles lie on the diagonal and on the
+    // window's edge).  Measured on MI355X, h32/8 d128, one ragged call (tools/perf_mixed.py and a
+    // batch of 8192 ... 127 tokens): 60 x 1 + 4 x 512 positions 722 -> 347 us; 80 x 300 causal 198 ->
+    // 181; window 1024 + ALiBi 610 -> 537, without ALiBi 497 -> 478; window 4096 1022 -> 1002; 24 x 1024
+    // causal level; long causal sequences 1.6 % behind (they keep one block per query head).
+    const bool short_ragged = k.h_ratio > 1 && !(vfa::g_tuning[2] & 4) && p->cu_seqlens_q && k.seqlen_q >= 128 &&
+                              ((p->total_q > 0 && (long long)p->total_q < 512LL * k.b) || k.is_local ||
+                               (vfa::g_tuning[2] & 8));
     if ((pack_rows_shape(k.h_ratio, k.seqlen_q) || short_ragged) && !(k.knew && k.rotary_dim > 0) &&
         vfa::fwd_prefill_pack_ok(k)) {
         e = vfa::run_fwd_prefill_pack(k, stream);

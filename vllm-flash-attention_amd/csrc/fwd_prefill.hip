@@ -519,7 +519,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
     float alibi = 0.f;
     const bool has_alibi = p.alibi_slopes != nullptr;
-    if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + bidh] / p.scale;
+    // (PACK: the slope of the lane's own head)
+    if (has_alibi) alibi = p.alibi_slopes[(int64_t)bidb * p.alibi_bs + head0 + row_head(q0w + r)] / p.scale;
     // ALiBi in LINEAR form.  Under a causal mask, or a window that ends at the diagonal or before,
     // every visible key has col <= row + sk - sq, so the bias -slope |row + sk - sq - col| is
     // slope * col plus a constant of the row, and a constant of the row cancels in the softmax.
@@ -529,7 +530,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     // reference itself adds slope * col (mask.h:180-181), - slope * (row + sk - sq - cref) under
     // a window (mask.h:183).
     const bool alibi_lin = has_alibi && (p.is_causal || (p.is_local && p.wr <= 0));
-    const int cref = m_block * BM + sk - sq;
+    const int cref = pos_lo_b + sk - sq;
     const float c2 = p.scale_log2;
 
     // per-lane LDS read offsets (see the note at st_off)
@@ -825,7 +826,7 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     float lse = bad ? (SPLIT ? -INFINITY : INFINITY) : m_run * p.scale + __logf(l_tot);
     if (alibi_lin && !bad) {  // the row constant left out of the linear ALiBi form
         const float slope = alibi * p.scale;
-        lse += p.is_causal ? slope * (float)cref : -slope * (float)(q0w + r + sk - sq - cref);
+        lse += p.is_causal ? slope * (float)cref : -slope * (float)(pos_l + sk - sq - cref);
     }
     if (hh == 0 && q0w + r < sq_rows) lse_g[stat_off(q0w + r)] = lse;
 
@@ -934,7 +935,7 @@ static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
 // unit of its own (fwd_prefill_pack.hip).  Every head dim, contiguous K/V or pages of a power of two;
 // with or without a split of the keys.
 bool fwd_prefill_pack_ok(const KParams &p) {
-    if (p.h_ratio <= 1 || p.alibi_slopes) return false;
+    if (p.h_ratio <= 1) return false;
     return kv_fits_buffer(p) || paged_fits_direct<128>(p);   // (the page test does not depend on the head dim)
 }
 template <int DP, bool BF16, bool SPLIT>
