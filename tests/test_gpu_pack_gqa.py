@@ -191,3 +191,26 @@ def test_mixed_serving_batch_short_on_average(paged):
     with cabi.dev(2, 4):   # one block per query head
         o0 = (cabi.fwd(q, kp, vp, block_table=bt, **kw) if paged else cabi.fwd(q, k, v, **kw))[0]
     assert np.abs(_f(out) - _f(o0)).max() <= 2 * ulp_tol("bf16", ro)
+
+
+@pytest.mark.parametrize("causal,window", [(True, (-1, -1)), (False, (-1, -1)), (False, (100, 20)), (True, (64, 0))])
+def test_packed_rows_with_alibi(causal, window):
+    """ALiBi under the packing: the slope is the one of the row's own head (a per-lane value), in the
+    linear form under a causal mask or a window that ends at the diagonal (the row constant goes back
+    into the LSE) and in the |i - j| form otherwise."""
+    import cabi
+    from oracle import fa_oracle
+    torch.manual_seed(17)
+    b, sq, sk, h, hk, d = 2, 40, 600, 8, 2, 128
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    slopes = torch.rand(b, h, device="cuda") * 0.3
+    out, lse = cabi.fwd(q, k, v, causal=causal, window=window, alibi_slopes=slopes)[:2]
+    ro, rl = fa_oracle.attention_fwd(_f(q), _f(k), _f(v), dtype="bf16", causal=causal, window=window, alibi_slopes=_f(slopes))
+    _check(out, lse, ro, rl, "bf16")
+    with cabi.dev(2, 4):
+        o0, l0 = cabi.fwd(q, k, v, causal=causal, window=window, alibi_slopes=slopes)[:2]
+    from gpu_util import ulp_tol
+    assert np.abs(_f(out) - _f(o0)).max() <= 2 * ulp_tol("bf16", ro)
+    assert np.abs(lse.cpu().numpy() - l0.cpu().numpy()).max() <= 2e-3
