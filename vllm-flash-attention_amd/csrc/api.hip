@@ -282,8 +282,11 @@ static int launch_fwd(const vfa_params *p, KParams &k, bool force_split) {
     // batch of 8192 ... 127 tokens): 60 x 1 + 4 x 512 positions 722 -> 347 us; 80 x 300 causal 198 ->
     // 181; window 1024 + ALiBi 610 -> 537, without ALiBi 497 -> 478; window 4096 1022 -> 1002; 24 x 1024
     // causal level; long causal sequences 1.6 % behind (they keep one block per query head).
+    // (Above d = 128 the unpacked rows have the hand-pipelined kernel, the packed ones the general
+    // one: there only batches of mostly one-block sequences are packed.)
+    const long long avg_lim = k.d <= 128 ? 512 : 128;
     const bool short_ragged = k.h_ratio > 1 && !(vfa::g_tuning[2] & 4) && p->cu_seqlens_q && k.seqlen_q >= 128 &&
-                              ((p->total_q > 0 && (long long)p->total_q < 512LL * k.b) || k.is_local ||
+                              ((p->total_q > 0 && (long long)p->total_q < avg_lim * k.b) || (k.is_local && k.d <= 128) ||
                                (vfa::g_tuning[2] & 8));
     if ((pack_rows_shape(k.h_ratio, k.seqlen_q) || short_ragged) && !(k.knew && k.rotary_dim > 0) &&
         vfa::fwd_prefill_pack_ok(k)) {
