@@ -214,3 +214,24 @@ def test_packed_rows_with_alibi(causal, window):
     from gpu_util import ulp_tol
     assert np.abs(_f(out) - _f(o0)).max() <= 2 * ulp_tol("bf16", ro)
     assert np.abs(lse.cpu().numpy() - l0.cpu().numpy()).max() <= 2e-3
+
+
+def test_python_varlen_api_passes_the_row_count_hint():
+    """flash_attn_varlen_func on a mixed batch: the extension hands q.size(0) to the library
+    (vfa_params.total_q), so the call equals the C-ABI call that sets it (packed rows), bit for bit."""
+    import cabi
+    import vllm_flash_attn as fa
+    torch.manual_seed(3)
+    ql, kl = [1] * 6 + [200], [300, 64, 1000, 17, 128, 555, 200]
+    h, hk, d = 8, 2, 128
+    cu = lambda l: torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device="cuda")
+    cq, ck = cu(ql), cu(kl)
+    q = torch.randn(sum(ql), h, d, device="cuda", dtype=torch.float16)
+    k = torch.randn(sum(kl), hk, d, device="cuda", dtype=torch.float16)
+    v = torch.randn_like(k)
+    out = fa.flash_attn_varlen_func(q, k, v, cq, ck, max(ql), max(kl), causal=True)
+    ref = cabi.fwd(q, k, v, causal=True, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql), max_seqlen_k=max(kl))[0]
+    assert torch.equal(out, ref)
+    with cabi.dev(2, 4):
+        unpacked = cabi.fwd(q, k, v, causal=True, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max(ql), max_seqlen_k=max(kl))[0]
+    assert (out.float() - unpacked.float()).abs().max().item() <= 2.0 ** -9 * max(1.0, unpacked.float().abs().max().item())
