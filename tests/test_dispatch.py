@@ -44,7 +44,7 @@ CASES = [
     ((1, 4096, 4096, 8, 8, 128, True), (B4, B4, B4)),        # 128 blocks of 256 rows on 256 CUs: 128-row blocks
     ((1, 4096, 4096, 8, 8, 128, False), (B4, B4, B4)),
     ((2, 1024, 1024, 16, 16, 128, False), (B4, B4, B4)),
-    ((1, 16384, 16384, 8, 8, 128, True), (P8, B8, P8)),      # 512 blocks: two per CU
+    ((1, 16384, 16384, 8, 8, 128, True), (P8, W64, P8)),     # 512 blocks: two per CU; dK/dV: 64 keys per wave from 12288 under a causal mask
     ((1, 16384, 16384, 8, 8, 128, False), (P8, W64, P8)),
     ((2, 4096, 4096, 16, 16, 128, True), (P8, B8, P8)),
     ((32, 512, 512, 16, 16, 128, True), (P8, B4, P8)),       # short sequences: dK/dV in 128-key blocks

@@ -127,3 +127,23 @@ def test_forced_64_key_kernel_masks_and_small_head_dims(case):
         eps = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
         for a, a8 in ((dk, dk8), (dv, dv8)):
             assert np.abs(_f(a) - _f(a8)).max() <= 2 * eps * max(1.0, np.abs(_f(a8)).max())
+
+
+def test_shipped_dispatch_very_long_causal_sequences_equal_the_8_wave_kernel():
+    """From 12288 keys under a causal mask the shipped dispatch takes the 64-key kernel too (its waves
+    cannot skip the pieces above the diagonal, which only pays back on long sweeps): same bits as the
+    8-wave kernel, whose masks the oracle checks at sizes it can reach."""
+    import cabi
+    torch.manual_seed(5)
+    b, s, h, d = 1, 12400, 11, 128
+    q = torch.randn(b, s, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn_like(q)
+    v = torch.randn_like(q)
+    do = torch.randn_like(q)
+    out, lse = cabi.fwd(q, k, v, causal=True)
+    assert cabi.lib().vfa_dispatch_geometry is not None
+    dq, dk, dv, _ = cabi.bwd(do, q, k, v, out, lse, causal=True, head_splits=1)
+    with cabi.dev(0, 1):
+        dq8, dk8, dv8, _ = cabi.bwd(do, q, k, v, out, lse, causal=True, head_splits=1)
+    assert not torch.isnan(dk).any() and not torch.isnan(dv).any()
+    assert torch.equal(dk, dk8) and torch.equal(dv, dv8) and torch.equal(dq, dq8)

@@ -14,7 +14,8 @@ SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 4096,
           (16, 1024, 16, 16, 128, True), (4, 2048, 16, 16, 64, True),
           (4, 4096, 32, 32, 64, False), (4, 4096, 32, 32, 64, True), (16, 1024, 32, 32, 64, True),   # 5, 6, 7
           (32, 512, 16, 16, 128, True), (32, 512, 32, 32, 64, False),                                 # 8, 9
-          (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False)]                                # 10, 11
+          (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False),                                # 10, 11
+          (2, 8192, 32, 32, 128, True), (1, 16384, 32, 32, 128, True), (2, 16384, 16, 16, 128, True)]  # 12, 13, 14
 
 
 def main():

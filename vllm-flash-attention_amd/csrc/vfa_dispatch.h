@@ -93,10 +93,13 @@ inline int dkdv_geometry(const KParams &p, const int cus) {
     if (kblocks < cus || p.seqlen_k <= 1024) return VFA_GEO_BLOCK4;
     if ((p.is_causal || p.is_local) && kblocks < 2LL * cus) return VFA_GEO_BLOCK4;   // one masked block per CU
     // 64 keys per wave at one wave per SIMD: full attention over long key ranges (+1-5 % from seqlen
-    // 4096; at 2048 between -3 and +2 %); level under a causal mask, where its waves cannot skip the
-    // pieces above the diagonal
-    if (w64_ok && g_tuning[0] == 0 && !p.is_causal && !p.is_local && p.seqlen_k >= 3072 && p.seqlen_q >= 3072)
-        return VFA_GEO_WAVE64;
+    // 4096; at 2048 between -3 and +2 %).  Under a causal mask its waves cannot skip the pieces above
+    // the diagonal, four 64-row steps per 256-key block: 7 % behind at seqlen 4096, 2 % at 8192, 3 %
+    // ahead at 16384 (b1 h32 3.757 -> 3.648 ms).
+    if (w64_ok && g_tuning[0] == 0 && !p.is_local) {
+        const int from = p.is_causal ? 12288 : 3072;
+        if (p.seqlen_k >= from && p.seqlen_q >= from) return VFA_GEO_WAVE64;
+    }
     return VFA_GEO_BLOCK8;
 }
 
