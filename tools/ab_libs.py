@@ -60,13 +60,14 @@ def main():
                 assert hd.vfa_mha_bwd(C.byref(Pb)) == 0
                 torch.cuda.synchronize()
                 if rnd >= 2:
-                    times[i].append((hip.elapsed_ms(C.c_void_p(ev[1]), C.c_void_p(ev[2])),
-                                     hip.elapsed_ms(C.c_void_p(ev[2]), C.c_void_p(ev[3]))))
+                    t = [hip.elapsed_ms(C.c_void_p(ev[j]), C.c_void_p(ev[j + 1])) for j in range(3)]
+                    times[i].append(t + [hip.elapsed_ms(C.c_void_p(ev[0]), C.c_void_p(ev[3]))])
         med = lambda xs: sorted(xs)[len(xs) // 2]
         print(f"b{b} s{s} h{h}/{hk} d{d} causal={causal}:", flush=True)
         for i, path in enumerate(libs):
-            print(f"   {os.path.basename(path):28s} dkdv {med([x[0] for x in times[i]]):.3f} ms   dq {med([x[1] for x in times[i]]):.3f} ms",
-                  flush=True)
+            n1, n2 = "dkdv", "dq"
+            m = [med([x[j] for x in times[i]]) for j in range(4)]
+            print(f"   {os.path.basename(path):28s} pre {m[0]:.3f}   {n1} {m[1]:.3f}   {n2} {m[2]:.3f}   all {m[3]:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
