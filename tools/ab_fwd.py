@@ -14,7 +14,8 @@ SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 8192,
           (4, 2048, 16, 16, 64, True), (32, 512, 16, 16, 128, True), (16, 1024, 16, 16, 128, False),
           (8, 2048, 32, 32, 64, False), (32, 512, 32, 32, 64, True), (4, 4096, 32, 32, 64, True),   # 7, 8
           (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False), (16, 1024, 8, 8, 256, True),   # 9, 10, 11
-          (16, 2048, 64, 8, 128, False), (16, 2048, 64, 8, 128, True)]   # 12, 13: the shape of the programming guide's forward example
+          (16, 2048, 64, 8, 128, False), (16, 2048, 64, 8, 128, True),   # 12, 13: the shape of the programming guide's forward example
+          (8, 4096, 32, 32, 96, True), (8, 4096, 32, 32, 96, False), (32, 512, 32, 32, 96, True), (8, 4096, 32, 32, 80, True)]   # 14-17
 
 
 def main():
@@ -47,6 +48,13 @@ def main():
             lse = torch.empty(b, h, s, device="cuda", dtype=torch.float32)
             P = bench.build_params(cabi, q, k, v, out, lse, causal, stream)
             times = [[] for _ in handles]
+            outs = []
+            for hd in handles:   # the builds must agree bit for bit
+                out.fill_(float("nan"))
+                assert hd.vfa_mha_fwd(C.byref(P)) == 0
+                outs.append(out.clone())
+            if not all(torch.equal(outs[0], o) for o in outs[1:]):
+                print("   OUTPUTS DIFFER, max", max((outs[0].float() - o.float()).abs().max().item() for o in outs[1:]), flush=True)
             for rnd in range(14):
                 for i, hd in enumerate(handles):
                     e0, e1 = hip.event(), hip.event()

@@ -148,8 +148,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     constexpr bool FAST = LD == 1 || DIRECT, PAGED_BUF = LD == 2 || PDIRECT;
     using Cfg = PrefillCfg<DP, BF16, NW>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
+#ifdef EXP_DV
+    constexpr int KS = (DP == 128 ? EXP_DV : DP) / 16;
+    constexpr int NDB = (DP == 128 ? EXP_DV : DP) / 32;
+#else
     constexpr int KS = DP / 16;   // k-steps of QK^T
     constexpr int NDB = DP / 32;  // 32-wide d blocks of O
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -664,7 +669,20 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 
         STAMP(1);
         // ---- masks and ALiBi, only where needed (mask.h:128-209) ----
-        if (need && !has_alibi && !p.is_local) {
+        // Each form sits behind a branch of its own that the usual tile walks around.  As
+        // alternatives of one if / else chain they made the compiler give the join its own 32
+        // registers and move every score into them on the path that needs no mask at all
+        // (16 v_mov_b64 per tile: 5-6 % of the forward's time at d = 64 and d = 128).
+        if (alibi_lin && !need_mask) {
+            // interior tile: bias only
+            const float t = alibi * (float)(c0 + 4 * hh - cref);
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; kb2++)
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    s[kb2][j] = __builtin_fmaf(alibi, (float)(32 * kb2 + (j & 3) + 8 * (j >> 2)), s[kb2][j] + t);
+        }
+        if (need_mask && !has_alibi && !p.is_local) {
             // causal diagonal and / or key tail only: key offset of register j (a constant) against
             // one per-lane limit -- a compare and a select per score
             const int hi = p.is_causal ? min(sk, pos_l + 1 + sk - sq) : sk;
@@ -674,25 +692,8 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     s[kb2][j] = (32 * kb2 + (j & 3) + 8 * (j >> 2) < lim) ? s[kb2][j] : -INFINITY;
-            if constexpr (SPEC) {
-                mx = s[0][0];
-#pragma unroll
-                for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
-            }
-        } else if (alibi_lin && !need_mask) {
-            // interior tile: bias only
-            const float t = alibi * (float)(c0 + 4 * hh - cref);
-#pragma unroll
-            for (int kb2 = 0; kb2 < 2; kb2++)
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    s[kb2][j] = __builtin_fmaf(alibi, (float)(32 * kb2 + (j & 3) + 8 * (j >> 2)), s[kb2][j] + t);
-            if constexpr (SPEC) {
-                mx = s[0][0];
-#pragma unroll
-                for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);
-            }
-        } else if (need) {
+        }
+        if ((need_mask && (has_alibi || p.is_local)) || (has_alibi && !alibi_lin && !need_mask)) {
             const int row = pos_l;
             const int lo = p.is_local ? max(0, row + sk - sq - p.wl) : 0;
             const int hi = (p.is_causal || p.is_local) ? min(sk, row + 1 + sk - sq + p.wr) : sk;
@@ -707,7 +708,9 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
                                       : x - alibi * fabsf((float)(row + sk - sq - col));
                     s[kb2][j] = (col >= lo && col < hi) ? x : -INFINITY;
                 }
-            if constexpr (SPEC) {
+        }
+        if constexpr (SPEC) {
+            if (need) {   // the early maximum was taken on scores without mask or bias
                 mx = s[0][0];
 #pragma unroll
                 for (int j = 1; j < 16; j++) mx = fmaxf(mx, s[0][j]);

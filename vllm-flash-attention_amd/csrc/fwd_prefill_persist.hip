@@ -48,7 +48,11 @@ __global__ void __launch_bounds__(NW_ * 64, (PersistCfg<DP_, NW_>::WG_PER_CU))
 fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_items) {
     using Cfg = PersistCfg<DP_, NW_>;
     constexpr int DP = Cfg::DP, NW = Cfg::NW, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, CPR = Cfg::CPR;
+#ifdef EXP_DV
+    constexpr int KS = (DP == 128 ? EXP_DV : DP) / 16, NDB = (DP == 128 ? EXP_DV : DP) / 32;
+#else
     constexpr int KS = DP / 16, NDB = DP / 32;
+#endif
     constexpr int RPI = 64 / CPR;                 // rows per wave instruction of a direct-to-LDS load
     constexpr int NI = BN / (RPI * NW);           // instructions per wave, tile and tensor
     constexpr int ROWB = DP * 2;
