@@ -138,7 +138,7 @@ struct PrefillCfg {
 // heads).  For a few query tokens per sequence against a long cache (chunked prefill, draft-token
 // verification): 16 tokens of 4 grouped heads fill half a 128-row block and sweep the keys once,
 // where one block per query head sweeps them four times at an eighth of the rows each.
-template <int DP, bool BF16, int NW, int LD, bool DROP, bool SPLIT = false, bool PACK = false>
+template <int DP, bool BF16, int NW, int LD, bool DROP, bool SPLIT = false, bool PACK = false, int DV = DP>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     static_assert(!PACK || (NW == 4 && !DROP), "packed grouped heads: 4-wave geometry, no dropout");
@@ -148,13 +148,11 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     constexpr bool FAST = LD == 1 || DIRECT, PAGED_BUF = LD == 2 || PDIRECT;
     using Cfg = PrefillCfg<DP, BF16, NW>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
-#ifdef EXP_DV
-    constexpr int KS = (DP == 128 ? EXP_DV : DP) / 16;
-    constexpr int NDB = (DP == 128 ? EXP_DV : DP) / 32;
-#else
-    constexpr int KS = DP / 16;   // k-steps of QK^T
-    constexpr int NDB = DP / 32;  // 32-wide d blocks of O
-#endif
+    // DV <= DP: the head dims this instantiation serves, rounded up to 32.  The tiles keep the
+    // layout of DP columns (zero beyond the head dim); the products stop at column DV.
+    static_assert(DV % 32 == 0 && DV <= DP && 2 * DV > DP, "DV");
+    constexpr int KS = DV / 16;   // k-steps of QK^T
+    constexpr int NDB = DV / 32;  // 32-wide d blocks of O
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -874,13 +872,13 @@ fwd_prefill_kernel(const KParams p, const int n_mblocks) {
     FWD_BLK_STAMP(3);
 }
 
-template <int DP, bool BF16, int NW, int LD, bool DROP = false, bool SPLIT = false, bool PACK = false>
+template <int DP, bool BF16, int NW, int LD, bool DROP = false, bool SPLIT = false, bool PACK = false, int DV = DP>
 static hipError_t launch_prefill_impl(const KParams &p, hipStream_t stream) {
     using Cfg = PrefillCfg<DP, BF16, NW>;
     const int n_mblocks = (p.seqlen_q * (PACK ? p.pack_gqa : 1) + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;   // (PACK: p.h is the KV head count)
     if (blocks <= 0) return hipSuccess;
-    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP, SPLIT, PACK>;
+    auto kern = fwd_prefill_kernel<DP, BF16, NW, LD, DROP, SPLIT, PACK, DV>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, SPLIT ? (unsigned)p.num_splits : 1u), dim3(Cfg::NT),
@@ -914,22 +912,22 @@ static bool paged_fits_direct(const KParams &p) {
            (int64_t)p.page_size * p.k_rs * 2 < lim && (int64_t)p.page_size * p.v_rs * 2 < lim;
 }
 
-#if (!defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)) || defined(VFA_FWD64_TU)
-template <int DP, bool BF16, int NW>
+#if (!defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)) || defined(VFA_FWD64_TU) || defined(VFA_FWD96_TU)
+template <int DP, bool BF16, int NW, int DV = DP>
 static hipError_t launch_prefill(const KParams &p, hipStream_t stream) {
     // contiguous K/V: straight into LDS where the lane map allows it (measured on MI355X against
     // register staging: +2..4 % at seqlen 4096, +9 % at 512..2048, d = 64 +4 %)
-    if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, 3>(p, stream);
+    if (kv_fits_buffer(p)) return launch_prefill_impl<DP, BF16, NW, 3, false, false, false, DV>(p, stream);
     // paged K/V through per-page descriptors: straight into LDS (measured against register staging,
     // b4 s4096 h16 causal: page 256 d = 64 633 -> 742, d = 128 854 -> 879 TFLOP/s; above d = 128 the
     // staging registers do not fit).  Development switch 5 = 1 takes register staging.
     if (paged_fits_direct<DP>(p) && !(g_tuning[5] == 1 && DP <= 128 && paged_fits_buffer<DP, NW>(p)))
-        return launch_prefill_impl<DP, BF16, NW, 4>(p, stream);
+        return launch_prefill_impl<DP, BF16, NW, 4, false, false, false, DV>(p, stream);
 #ifdef VFA_DEV   // register staging of paged tiles: reachable only through development switch 5
     if constexpr (DP <= 128)
-        if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2>(p, stream);
+        if (paged_fits_buffer<DP, NW>(p)) return launch_prefill_impl<DP, BF16, NW, 2, false, false, false, DV>(p, stream);
 #endif
-    return launch_prefill_impl<DP, BF16, NW, 0>(p, stream);
+    return launch_prefill_impl<DP, BF16, NW, 0, false, false, false, DV>(p, stream);
 }
 
 #endif
@@ -970,9 +968,20 @@ hipError_t run_fwd_prefill_pack(const KParams &p_in, hipStream_t stream) {
 hipError_t run_fwd_prefill_64(const KParams &p, hipStream_t stream) {
     return p.is_bf16 ? launch_prefill<64, true, 4>(p, stream) : launch_prefill<64, false, 4>(p, stream);
 }
+#elif defined(VFA_FWD96_TU)
+// Head dims 65..96, a translation unit of their own (fwd_prefill_d96.hip): the d = 128 tile layout
+// with the products cut off at column 96 (6 of 8 k-steps of Q K^T, 3 of 4 column blocks of P V; the
+// skipped ones multiply zero padding, so the results are the same bits).  Measured b8 s4096 h32 d96
+// causal 1.120 -> 1.042 ms, full 1.915 -> 1.831, d80 causal 1.034 -> 0.978.
+hipError_t run_fwd_prefill_96(const KParams &p, hipStream_t stream, bool waves8) {
+    const bool bf = p.is_bf16;
+    if (waves8) return bf ? launch_prefill<128, true, 8, 96>(p, stream) : launch_prefill<128, false, 8, 96>(p, stream);
+    return bf ? launch_prefill<128, true, 4, 96>(p, stream) : launch_prefill<128, false, 4, 96>(p, stream);
+}
 #elif !defined(VFA_DROPOUT_TU) && !defined(VFA_SPLIT_TU)
 // Tile choice per head dim (the counterpart of flash_fwd_launch_template.h:168-370).
 hipError_t run_fwd_prefill_64(const KParams &p, hipStream_t stream);          // fwd_prefill_d64.hip
+hipError_t run_fwd_prefill_96(const KParams &p, hipStream_t stream, bool waves8);   // fwd_prefill_d96.hip
 bool fwd_prefill_w64_ok(const KParams &p);
 hipError_t run_fwd_prefill_w64(const KParams &p, hipStream_t stream);
 
@@ -1001,6 +1010,7 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
     // TFLOP/s, full 1013 -> 1077; b4 s8192 h32/8 causal 1010 -> 1060; b32 s512 h16 causal 477 -> 529;
     // b16 s1024 h16 full 869 -> 960.
     if (geo == VFA_GEO_PERSIST8) return run_fwd_prefill_persist(p, stream, 0);
+    if (p.d <= 96) return run_fwd_prefill_96(p, stream, geo == VFA_GEO_BLOCK8);
     if (geo == VFA_GEO_BLOCK8) return bf ? launch_prefill<128, true, 8>(p, stream) : launch_prefill<128, false, 8>(p, stream);
     return bf ? launch_prefill<128, true, 4>(p, stream) : launch_prefill<128, false, 4>(p, stream);
 }

@@ -43,16 +43,15 @@ struct PersistCfg {
     static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS per CU");
 };
 
-template <int DP_, bool BF16, int NW_>
+template <int DP_, bool BF16, int NW_, int DV = DP_>
 __global__ void __launch_bounds__(NW_ * 64, (PersistCfg<DP_, NW_>::WG_PER_CU))
 fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_items) {
     using Cfg = PersistCfg<DP_, NW_>;
     constexpr int DP = Cfg::DP, NW = Cfg::NW, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, CPR = Cfg::CPR;
-#ifdef EXP_DV
-    constexpr int KS = (DP == 128 ? EXP_DV : DP) / 16, NDB = (DP == 128 ? EXP_DV : DP) / 32;
-#else
-    constexpr int KS = DP / 16, NDB = DP / 32;
-#endif
+    // DV <= DP: the head dims this instantiation serves, rounded up to 32 (tiles keep the layout
+    // of DP columns, the products stop at column DV: the rest would multiply zero padding)
+    static_assert(DV % 32 == 0 && DV <= DP && 2 * DV > DP, "DV");
+    constexpr int KS = DV / 16, NDB = DV / 32;
     constexpr int RPI = 64 / CPR;                 // rows per wave instruction of a direct-to-LDS load
     constexpr int NI = BN / (RPI * NW);           // instructions per wave, tile and tensor
     constexpr int ROWB = DP * 2;
@@ -216,6 +215,7 @@ fwd_prefill_persist_kernel(const KParams p, const int n_mblocks, const int n_ite
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++) {
                     const int db = 2 * half + d2;
+                    if (db >= NDB) continue;   // (a column block beyond DV: never stored)
                     i32x2 w;
                     w[0] = pack2<BF16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
                     w[1] = pack2<BF16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
@@ -421,7 +421,7 @@ long long fwd_prefill_persist_items(const KParams &p, int waves_override) {
     return (long long)((p.seqlen_q + bm - 1) / bm) * p.b * p.h;
 }
 
-template <int DP, bool BF16, int NW>
+template <int DP, bool BF16, int NW, int DV = DP>
 static hipError_t launch_persist(const KParams &p, hipStream_t stream) {
     using Cfg = PersistCfg<DP, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
@@ -430,7 +430,7 @@ static hipError_t launch_persist(const KParams &p, hipStream_t stream) {
     if (items > 0x7fffffffLL) return hipErrorInvalidValue;
     // as many workgroups as stay resident, a multiple of 8 (whole rounds over the XCDs)
     const int grid = std::max(8, device_num_cus() / 8 * 8) * Cfg::WG_PER_CU;
-    auto kern = fwd_prefill_persist_kernel<DP, BF16, NW>;
+    auto kern = fwd_prefill_persist_kernel<DP, BF16, NW, DV>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks, (int)items);
@@ -446,6 +446,8 @@ hipError_t run_fwd_prefill_persist(const KParams &p, hipStream_t stream, int wav
     }
 #endif
     if (p.d <= 64) return hipErrorInvalidValue;
+    // head dims 65..96: 6 of 8 k-steps, 3 of 4 column blocks (b8 s4096 h32 d96 causal 1.120 -> 1.042 ms)
+    if (p.d <= 96) return bf ? launch_persist<128, true, 8, 96>(p, stream) : launch_persist<128, false, 8, 96>(p, stream);
     return bf ? launch_persist<128, true, 8>(p, stream) : launch_persist<128, false, 8>(p, stream);
 }
 
