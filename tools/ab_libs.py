@@ -15,7 +15,8 @@ SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 4096,
           (4, 4096, 32, 32, 64, False), (4, 4096, 32, 32, 64, True), (16, 1024, 32, 32, 64, True),   # 5, 6, 7
           (32, 512, 16, 16, 128, True), (32, 512, 32, 32, 64, False),                                 # 8, 9
           (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False),                                # 10, 11
-          (2, 8192, 32, 32, 128, True), (1, 16384, 32, 32, 128, True), (2, 16384, 16, 16, 128, True)]  # 12, 13, 14
+          (2, 8192, 32, 32, 128, True), (1, 16384, 32, 32, 128, True), (2, 16384, 16, 16, 128, True),  # 12, 13, 14
+          (8, 4096, 32, 32, 96, True), (8, 4096, 32, 32, 96, False), (32, 512, 32, 32, 96, True), (8, 4096, 32, 32, 80, True)]  # 15-18
 
 
 def main():
@@ -53,6 +54,15 @@ def main():
         cabi.call("vfa_mha_fwd", bench.build_params(cabi, q, k, v, out, lse, causal, stream))
         Pb = bench.build_params(cabi, q, k, v, out, lse, causal, stream, do, dq, dk, dv, sd, acc)
         times = [[] for _ in handles]
+        grads = []
+        for hd in handles:   # the builds must agree bit for bit
+            Pb.stage_events = None
+            for t in (dq, dk, dv):
+                t.fill_(float("nan"))
+            assert hd.vfa_mha_bwd(C.byref(Pb)) == 0
+            grads.append((dq.clone(), dk.clone(), dv.clone()))
+        if not all(all(torch.equal(a, b_) for a, b_ in zip(grads[0], g)) for g in grads[1:]):
+            print("   GRADIENTS DIFFER", flush=True)
         for rnd in range(9):
             for i, hd in enumerate(handles):
                 ev = (C.c_void_p * 4)(*[hip.event() for _ in range(4)])

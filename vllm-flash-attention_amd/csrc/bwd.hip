@@ -180,12 +180,15 @@ struct BwdCfg {
     static constexpr int PP_LDS_BYTES = LDS_BYTES + (NW / 2) * PP_KLDS * 1024;   // (waves 0-3 use the gap behind the ring)
 };
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false, int DV = DP>
 __global__ void __launch_bounds__(NW * 64, (BwdCfg<DP, NW>::WG_PER_CU))
 bwd_dkdv_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdCfg<DP, NW>;
     constexpr int CPR = Cfg::CPR, NT = Cfg::NT, KB = Cfg::KB;
-    constexpr int KS = DP / 16, NDB = DP / 32 / Cfg::DSPLIT;   // NDB: 32-column blocks of dK / dV held by this workgroup
+    // DV <= DP: the head dims this instantiation serves, rounded up to 32.  Tiles and fragments keep
+    // the layout of DP columns (zero beyond the head dim); the products stop at column DV.
+    static_assert(DV % 32 == 0 && DV <= DP && 2 * DV > DP, "DV");
+    constexpr int KS = DV / 16, NDB = DV / 32 / Cfg::DSPLIT;   // NDB: 32-column blocks of dK / dV held by this workgroup
     const int db0 = Cfg::DSPLIT > 1 ? (int)blockIdx.z * NDB : 0;   // its first block
     constexpr int QCH = Cfg::QCH, BW_QM = Cfg::QM, QSUB = Cfg::QSUB;
     constexpr bool V_IN_LDS = Cfg::V_IN_LDS;
@@ -1276,14 +1279,14 @@ static bool bwd_fits_buffer(const KParams &p) {
     return rq * p.q_rs * 2 < lim && rq * p.do_rs * 2 < lim && rk * p.k_rs * 2 < lim && rk * p.v_rs * 2 < lim;
 }
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, bool HS, bool PP = false, int DV = DP>
 static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
     using Cfg = BwdCfg<DP, NW>;
     constexpr int LDS = PP ? Cfg::PP_LDS_BYTES : Cfg::LDS_BYTES + (DROP ? NW * 1024 : 0);  // + the Philox exchange space
     const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS, PP>;
+    auto kern = bwd_dkdv_kernel<DP, BF16, NW, FAST, DROP, HS, PP, DV>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, LDS, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(HS ? p.hsplit : 1), (unsigned)Cfg::DSPLIT), dim3(Cfg::NT), LDS,
@@ -1291,10 +1294,10 @@ static hipError_t launch_dkdv_hs(const KParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP = false, int DV = DP>
 static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
 #ifdef VFA_DEV   // development build only: measured level with the default schedule
-    if constexpr (FAST && DP == 128 && NW == 8 && !DROP) {
+    if constexpr (FAST && DP == 128 && NW == 8 && !DROP && DV == DP) {
         // the two-phase schedule (PP in bwd_dkdv_kernel); development switch 0: 3 = always, 4 = never
         // Opt-in: measured level with the default schedule (2.12 vs 2.12 ms on b8 s4096 h32 d128
         // causal, 1.79 vs 1.80 ms on all-zero inputs): beside a partner's vector work the MFMAs
@@ -1309,18 +1312,18 @@ static hipError_t launch_dkdv_impl(const KParams &p, hipStream_t stream) {
                                 : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false, true>(p, stream);
     }
 #endif
-    return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true>(p, stream)
-                        : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false>(p, stream);
+    return p.hsplit > 1 ? launch_dkdv_hs<DP, BF16, NW, FAST, DROP, true, false, DV>(p, stream)
+                        : launch_dkdv_hs<DP, BF16, NW, FAST, DROP, false, false, DV>(p, stream);
 }
 
-template <int DP, bool BF16, int NW, bool DROP>
+template <int DP, bool BF16, int NW, bool DROP, int DV = DP>
 static hipError_t launch_dkdv(const KParams &p, hipStream_t stream) {
     if constexpr (DROP) {
         return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true, true>(p, stream)
                                   : launch_dkdv_impl<DP, BF16, NW, false, true>(p, stream);
     } else {
-        return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true>(p, stream)
-                                  : launch_dkdv_impl<DP, BF16, NW, false>(p, stream);
+        return bwd_fits_buffer(p) ? launch_dkdv_impl<DP, BF16, NW, true, false, DV>(p, stream)
+                                  : launch_dkdv_impl<DP, BF16, NW, false, false, DV>(p, stream);
     }
 }
 
@@ -1350,12 +1353,13 @@ struct DqCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
 };
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP, int DV = DP>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 || DP == 256) ? 1 : 2)
 bwd_dq_kernel(const KParams p, const int n_mblocks) {
     using Cfg = DqCfg<DP, NW>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, CPR = Cfg::CPR, CH = Cfg::CH;
-    constexpr int KS = DP / 16, NDB = DP / 32;
+    static_assert(DV % 32 == 0 && DV <= DP && 2 * DV > DP, "DV");   // (see bwd_dkdv_kernel)
+    constexpr int KS = DV / 16, NDB = DV / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -1720,27 +1724,27 @@ bwd_dq_kernel(const KParams p, const int n_mblocks) {
     DQ_STAMP(3);
 }
 
-template <int DP, bool BF16, int NW, bool FAST, bool DROP = false>
+template <int DP, bool BF16, int NW, bool FAST, bool DROP = false, int DV = DP>
 static hipError_t launch_dq_impl(const KParams &p, hipStream_t stream) {
     using Cfg = DqCfg<DP, NW>;
     const int n_mblocks = (p.seqlen_q + Cfg::BM - 1) / Cfg::BM;
     const long long blocks = (long long)n_mblocks * p.b * p.h;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dq_kernel<DP, BF16, NW, FAST, DROP>;
+    auto kern = bwd_dq_kernel<DP, BF16, NW, FAST, DROP, DV>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks);
     return hipGetLastError();
 }
 
-template <int DP, bool BF16, int NW>
+template <int DP, bool BF16, int NW, int DV = DP>
 static hipError_t launch_dq(const KParams &p, hipStream_t stream) {
-    return bwd_fits_buffer(p) ? launch_dq_impl<DP, BF16, NW, true>(p, stream)
-                              : launch_dq_impl<DP, BF16, NW, false>(p, stream);
+    return bwd_fits_buffer(p) ? launch_dq_impl<DP, BF16, NW, true, false, DV>(p, stream)
+                              : launch_dq_impl<DP, BF16, NW, false, false, DV>(p, stream);
 }
 
 hipError_t run_bwd_dkdv_w64(const KParams &p, hipStream_t stream);  // bwd_dkdv_w64.hip
-#if !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ_ILP_TU)
+#if !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ_ILP_TU) && !defined(VFA_BWD96_TU)
 // Whether the 64-keys-per-wave dK/dV kernel can run this problem.
 bool bwd_dkdv_w64_ok(const KParams &p) {
     return p.d <= 128 && p.hsplit <= 1 && p.seqlen_k > 128 && bwd_fits_buffer(p);
@@ -1756,7 +1760,7 @@ bool bwd_dq_persist_ok(const KParams &p);                            // bwd_dq_p
 long long bwd_dq_persist_items(const KParams &p);
 hipError_t run_bwd_dq_persist(const KParams &p, hipStream_t stream);
 
-template <int DP, bool BF16, bool DROP>
+template <int DP, bool BF16, bool DROP, int DV = DP>
 static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
     hipError_t e;
     if (ev && (e = hipEventRecord(ev[0], stream)) != hipSuccess) return e;
@@ -1782,7 +1786,7 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
     else if (geo_kv == VFA_GEO_WAVE64) e = run_bwd_dkdv_w64(p, stream);
     else if (geo_kv == VFA_GEO_WIDE32) e = run_bwd_dkdv_wide(p, stream);
     else if constexpr (DP == 256) e = launch_dkdv<DP, BF16, 4, DROP>(p, stream);
-    else e = geo_kv == VFA_GEO_BLOCK4 ? launch_dkdv<DP, BF16, 4, DROP>(p, stream) : launch_dkdv<DP, BF16, 8, DROP>(p, stream);
+    else e = geo_kv == VFA_GEO_BLOCK4 ? launch_dkdv<DP, BF16, 4, DROP, DV>(p, stream) : launch_dkdv<DP, BF16, 8, DROP, DV>(p, stream);
     if (e != hipSuccess) return e;
     if (p.hsplit > 1) {
         const int64_t items = p.part_rows * p.h_k * (p.d / 8);
@@ -1818,12 +1822,26 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
 hipError_t run_bwd_dq_ilp(const KParams &p, hipStream_t stream, bool waves8) {
     const bool bf = p.is_bf16;
     if (p.d > 128) return bf ? launch_dq<256, true, 4>(p, stream) : launch_dq<256, false, 4>(p, stream);
+    if (p.d <= 96) {   // products cut off at column 96 (see run_bwd_96)
+        if (waves8) return bf ? launch_dq<128, true, 8, 96>(p, stream) : launch_dq<128, false, 8, 96>(p, stream);
+        return bf ? launch_dq<128, true, 4, 96>(p, stream) : launch_dq<128, false, 4, 96>(p, stream);
+    }
     if (waves8) return bf ? launch_dq<128, true, 8>(p, stream) : launch_dq<128, false, 8>(p, stream);
     return bf ? launch_dq<128, true, 4>(p, stream) : launch_dq<128, false, 4>(p, stream);
 }
+#elif defined(VFA_BWD96_TU)
+// Head dims 65..96, a translation unit of their own (bwd_d96.hip): the d = 128 layouts with the
+// products cut off at column 96 -- 6 of 8 k-steps of S and dP, 3 of 4 column blocks of dK, dV and dQ;
+// the skipped ones multiply zero padding, so the gradients are the same bits.  Measured b8 s4096 h32
+// d96 causal: dK/dV 1.937 -> 1.666 ms, dQ 1.413 -> 1.235.
+hipError_t run_bwd_96(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
+    return p.is_bf16 ? launch_bwd<128, true, false, 96>(p, stream, ev) : launch_bwd<128, false, false, 96>(p, stream, ev);
+}
 #elif !defined(VFA_DROPOUT_TU)
+hipError_t run_bwd_96(const KParams &p, hipStream_t stream, hipEvent_t *ev);   // bwd_d96.hip
 hipError_t run_bwd(const KParams &p, hipStream_t stream, hipEvent_t *ev) {
     const bool bf = p.is_bf16;
+    if (p.d > 64 && p.d <= 96) return run_bwd_96(p, stream, ev);
     if (p.d <= 64) return bf ? launch_bwd<64, true, false>(p, stream, ev) : launch_bwd<64, false, false>(p, stream, ev);
     if (p.d <= 128) return bf ? launch_bwd<128, true, false>(p, stream, ev) : launch_bwd<128, false, false>(p, stream, ev);
     return bf ? launch_bwd<256, true, false>(p, stream, ev) : launch_bwd<256, false, false>(p, stream, ev);
@@ -1839,7 +1857,7 @@ hipError_t run_bwd_dropout(const KParams &p, hipStream_t stream, hipEvent_t *ev)
 
 }  // namespace vfa
 
-#if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ_ILP_TU)
+#if defined(VFA_STAMP) && !defined(VFA_DROPOUT_TU) && !defined(VFA_DQ_ILP_TU) && !defined(VFA_BWD96_TU)
 extern "C" __attribute__((visibility("default"))) int vfa_debug_read_stamps_dkdv(unsigned long long *host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vfa::g_stamps_dkdv), n * sizeof(unsigned long long));
 }

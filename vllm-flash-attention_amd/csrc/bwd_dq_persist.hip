@@ -38,12 +38,14 @@ struct DqPersistCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
 };
 
-template <bool BF16>
+template <bool BF16, int DV = DqPersistCfg::DP>
 __global__ void __launch_bounds__(DqPersistCfg::NT, 1)
 bwd_dq_persist_kernel(const KParams p, const int n_mblocks, const int n_items) {
     using Cfg = DqPersistCfg;
     constexpr int DP = Cfg::DP, NW = Cfg::NW, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, CPR = Cfg::CPR;
-    constexpr int KS = DP / 16, NDB = DP / 32;
+    // DV <= DP: head dims up to DV; the tiles keep the layout of DP columns, the products stop at DV
+    static_assert(DV % 32 == 0 && DV <= DP && 2 * DV > DP, "DV");
+    constexpr int KS = DV / 16, NDB = DV / 32;
     constexpr int RPI = 64 / CPR, NI = BN / (RPI * NW);
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -374,17 +376,17 @@ hipError_t run_bwd_dq_persist(const KParams &p, hipStream_t stream) {
     if (items <= 0) return hipSuccess;
     if (items > 0x7fffffffLL) return hipErrorInvalidValue;
     const int grid = std::max(8, device_num_cus() / 8 * 8);
-    static std::atomic<uint64_t> lds_set[2];
-    hipError_t e;
-    if (p.is_bf16) {
-        auto kern = bwd_dq_persist_kernel<true>;
-        if ((e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set[0])) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks, (int)items);
-    } else {
-        auto kern = bwd_dq_persist_kernel<false>;
-        if ((e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set[1])) != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_mblocks, (int)items);
-    }
+    // head dims 65..96: the products cut off at column 96 (b8 s4096 h32 d96 causal 1.413 -> 1.235 ms)
+    const bool cut = p.d <= 96;
+    static std::atomic<uint64_t> lds_set[4];
+    const void *kern = p.is_bf16 ? (cut ? (const void *)bwd_dq_persist_kernel<true, 96> : (const void *)bwd_dq_persist_kernel<true>)
+                                 : (cut ? (const void *)bwd_dq_persist_kernel<false, 96> : (const void *)bwd_dq_persist_kernel<false>);
+    if (hipError_t e = set_dyn_lds_once(kern, Cfg::LDS_BYTES, lds_set[2 * p.is_bf16 + cut]); e != hipSuccess) return e;
+    KParams pk = p;
+    int nm = n_mblocks, ni = (int)items;
+    void *args[] = {&pk, &nm, &ni};
+    if (hipError_t e = hipLaunchKernel(kern, dim3((unsigned)grid), dim3(Cfg::NT), args, Cfg::LDS_BYTES, stream); e != hipSuccess)
+        return e;
     return hipGetLastError();
 }
 

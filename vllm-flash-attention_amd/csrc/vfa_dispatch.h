@@ -96,7 +96,8 @@ inline int dkdv_geometry(const KParams &p, const int cus) {
     // 4096; at 2048 between -3 and +2 %).  Under a causal mask its waves cannot skip the pieces above
     // the diagonal, four 64-row steps per 256-key block: 7 % behind at seqlen 4096, 2 % at 8192, 3 %
     // ahead at 16384 (b1 h32 3.757 -> 3.648 ms).
-    if (w64_ok && g_tuning[0] == 0 && !p.is_local) {
+    // (head dims up to 96 stay with the 8-wave kernel, which stops its products at column 96)
+    if (w64_ok && g_tuning[0] == 0 && !p.is_local && p.d > 96) {
         const int from = p.is_causal ? 12288 : 3072;
         if (p.seqlen_k >= from && p.seqlen_q >= from) return VFA_GEO_WAVE64;
     }
