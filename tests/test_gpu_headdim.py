@@ -381,3 +381,43 @@ def test_padded_head_dim_in_the_eight_wave_kernels(case):
     grads = cabi.bwd(do, q, k, v, out, lse, **kw)[:3]
     ref = fa_oracle.attention_bwd(f32(do), f32(q), f32(k), f32(v), ro, rl, **okw)[:3]
     _check_grads(grads, ref, dt)
+
+
+# ---- head dims 65..96: the kernels stop their products at column 96 ----
+CUT96 = [
+    # b, sq, sk, h, hk, d, causal, window
+    (2, 777, 777, 4, 4, 96, True, (-1, -1)),
+    (2, 777, 1300, 4, 2, 80, False, (-1, -1)),        # grouped heads, key tail
+    (1, 2100, 2100, 8, 8, 72, True, (-1, -1)),
+    (2, 640, 900, 4, 1, 96, True, (300, 0)),          # sliding window: one block per workgroup
+    (16, 4096, 4096, 32, 32, 96, True, (-1, -1)),     # persistent forward and dQ, 8-wave dK/dV
+    (8, 4096, 4096, 32, 32, 96, False, (-1, -1)),     # full attention over long key ranges
+]
+
+
+@pytest.mark.parametrize("case", CUT96, ids=[str(c) for c in CUT96])
+def test_head_dims_up_to_96_equal_the_zero_padded_d128_call_bit_for_bit(case):
+    """A head dim of 65..96 runs the d = 128 tiles with the MFMA loops cut off at column 96.  What is
+    skipped multiplies zero padding, so the same tensors padded with zeros to d = 128 (which take the
+    full loops, and at these sizes partly other kernels) must give the same bits: output, LSE and
+    all three gradients."""
+    import cabi
+    import torch.nn.functional as F
+    b, sq, sk, h, hk, d, causal, window = case
+    torch.manual_seed(d + sq)
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn_like(q)
+    kw = dict(causal=causal, window=window, softmax_scale=d ** -0.5)
+    out, lse = cabi.fwd(q, k, v, **kw)
+    dq, dk, dv, sd = cabi.bwd(do, q, k, v, out, lse, **kw)
+    pad = lambda t: F.pad(t, (0, 128 - d))
+    out_p, lse_p = cabi.fwd(pad(q), pad(k), pad(v), **kw)
+    dq_p, dk_p, dv_p, sd_p = cabi.bwd(pad(do), pad(q), pad(k), pad(v), out_p, lse_p, **kw)
+    assert torch.equal(out, out_p[..., :d]) and not out_p[..., d:].any()
+    assert torch.equal(lse, lse_p) or torch.equal(torch.nan_to_num(lse), torch.nan_to_num(lse_p))
+    assert torch.equal(sd[:, :, :sq], sd_p[:, :, :sq])
+    for a, a_p in ((dq, dq_p), (dk, dk_p), (dv, dv_p)):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, a_p[..., :d]) and not a_p[..., d:].any()
