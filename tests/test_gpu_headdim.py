@@ -392,15 +392,22 @@ CUT96 = [
     (2, 640, 900, 4, 1, 96, True, (300, 0)),          # sliding window: one block per workgroup
     (16, 4096, 4096, 32, 32, 96, True, (-1, -1)),     # persistent forward and dQ, 8-wave dK/dV
     (8, 4096, 4096, 32, 32, 96, False, (-1, -1)),     # full attention over long key ranges
+    # head dims 129..192: the one-wave-per-SIMD kernels stop at column 160 or 192 of their 256
+    (2, 777, 777, 4, 4, 160, True, (-1, -1)),
+    (1, 1300, 2100, 4, 2, 144, False, (-1, -1)),
+    (2, 1500, 1500, 4, 1, 192, True, (-1, -1)),
+    (1, 2000, 2000, 2, 2, 176, True, (500, 0)),
+    (4, 4096, 4096, 16, 16, 192, True, (-1, -1)),
+    (2, 4096, 4096, 16, 4, 160, False, (-1, -1)),
 ]
 
 
 @pytest.mark.parametrize("case", CUT96, ids=[str(c) for c in CUT96])
-def test_head_dims_up_to_96_equal_the_zero_padded_d128_call_bit_for_bit(case):
-    """A head dim of 65..96 runs the d = 128 tiles with the MFMA loops cut off at column 96.  What is
-    skipped multiplies zero padding, so the same tensors padded with zeros to d = 128 (which take the
-    full loops, and at these sizes partly other kernels) must give the same bits: output, LSE and
-    all three gradients."""
+def test_cut_off_head_dims_equal_the_zero_padded_call_bit_for_bit(case):
+    """A head dim of 65..96 runs the d = 128 tiles with the MFMA loops cut off at column 96 (129..192:
+    the d = 256 tiles cut off at 160 or 192).  What is skipped multiplies zero padding, so the same
+    tensors padded with zeros to d = 128 (256), which take the full loops and at these sizes partly
+    other kernels, must give the same bits: output, LSE, softmax_d and all three gradients."""
     import cabi
     import torch.nn.functional as F
     b, sq, sk, h, hk, d, causal, window = case
@@ -412,7 +419,8 @@ def test_head_dims_up_to_96_equal_the_zero_padded_d128_call_bit_for_bit(case):
     kw = dict(causal=causal, window=window, softmax_scale=d ** -0.5)
     out, lse = cabi.fwd(q, k, v, **kw)
     dq, dk, dv, sd = cabi.bwd(do, q, k, v, out, lse, **kw)
-    pad = lambda t: F.pad(t, (0, 128 - d))
+    dp = 128 if d <= 128 else 256
+    pad = lambda t: F.pad(t, (0, dp - d))
     out_p, lse_p = cabi.fwd(pad(q), pad(k), pad(v), **kw)
     dq_p, dk_p, dv_p, sd_p = cabi.bwd(pad(do), pad(q), pad(k), pad(v), out_p, lse_p, **kw)
     assert torch.equal(out, out_p[..., :d]) and not out_p[..., d:].any()

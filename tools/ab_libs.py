@@ -16,7 +16,8 @@ SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 4096,
           (32, 512, 16, 16, 128, True), (32, 512, 32, 32, 64, False),                                 # 8, 9
           (4, 4096, 16, 16, 256, True), (4, 4096, 16, 16, 256, False),                                # 10, 11
           (2, 8192, 32, 32, 128, True), (1, 16384, 32, 32, 128, True), (2, 16384, 16, 16, 128, True),  # 12, 13, 14
-          (8, 4096, 32, 32, 96, True), (8, 4096, 32, 32, 96, False), (32, 512, 32, 32, 96, True), (8, 4096, 32, 32, 80, True)]  # 15-18
+          (8, 4096, 32, 32, 96, True), (8, 4096, 32, 32, 96, False), (32, 512, 32, 32, 96, True), (8, 4096, 32, 32, 80, True),  # 15-18
+          (4, 4096, 16, 16, 192, True), (4, 4096, 16, 16, 192, False), (4, 4096, 16, 16, 160, True), (4, 4096, 16, 16, 160, False)]  # 19-22
 
 
 def main():
