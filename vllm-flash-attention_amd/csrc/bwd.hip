@@ -1821,7 +1821,12 @@ static hipError_t launch_bwd(const KParams &p, hipStream_t stream, hipEvent_t *e
 // dK/dV kernels of this file spill.
 hipError_t run_bwd_dq_ilp(const KParams &p, hipStream_t stream, bool waves8) {
     const bool bf = p.is_bf16;
-    if (p.d > 128) return bf ? launch_dq<256, true, 4>(p, stream) : launch_dq<256, false, 4>(p, stream);
+    if (p.d > 128) {
+        // head dims up to 160 / 192 stop their products at that column
+        if (p.d <= 160) return bf ? launch_dq<256, true, 4, 160>(p, stream) : launch_dq<256, false, 4, 160>(p, stream);
+        if (p.d <= 192) return bf ? launch_dq<256, true, 4, 192>(p, stream) : launch_dq<256, false, 4, 192>(p, stream);
+        return bf ? launch_dq<256, true, 4>(p, stream) : launch_dq<256, false, 4>(p, stream);
+    }
     if (p.d <= 96) {   // products cut off at column 96 (see run_bwd_96)
         if (waves8) return bf ? launch_dq<128, true, 8, 96>(p, stream) : launch_dq<128, false, 8, 96>(p, stream);
         return bf ? launch_dq<128, true, 4, 96>(p, stream) : launch_dq<128, false, 4, 96>(p, stream);

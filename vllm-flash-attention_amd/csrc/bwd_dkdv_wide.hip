@@ -51,12 +51,15 @@ __device__ __forceinline__ void operand_fence2(i32x4 &a, i32x4 &b) {
     asm volatile("s_nop 1" : "+v"(a), "+v"(b));
 }
 
-template <bool BF16>
+template <bool BF16, int DV = BwdWideCfg::DP>
 __global__ void __launch_bounds__(256, 1)
 bwd_dkdv_wide_kernel(const KParams p, const int n_kblocks) {
     using Cfg = BwdWideCfg;
     constexpr int DP = Cfg::DP, CPR = Cfg::CPR, NT = Cfg::NT, KB = Cfg::KB, NW = Cfg::NW;
-    constexpr int KS = DP / 16, NDB = DP / 32, QM = Cfg::QM;
+    // DV <= DP: the head dims this instantiation serves, rounded up to 32.  Tiles, slices and fragments
+    // keep the layout of DP columns; the products stop at column DV (the rest multiplies zero padding)
+    static_assert(DV % 32 == 0 && DV <= DP && DV > 128, "DV");
+    constexpr int KS = DV / 16, NDB = DV / 32, QM = Cfg::QM;
     constexpr int ROWB = DP * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -296,7 +299,7 @@ bwd_dkdv_wide_kernel(const KParams p, const int n_kblocks) {
             s = mma32<BF16>(qa[ks], kf[ks], s);
 #pragma unroll
             for (int i = 0; i < Cfg::NI; i++)
-                if (ks == 1 + 3 * i) dma_round(i);
+                if (ks == 1 + i * (KS - 4) / Cfg::NI) dma_round(i);   // (k-steps 1, 4, 7, 10 of 16)
         }
         // The forward's mask and bias, on pieces that need them (wave-uniform).  Register j of lane
         // (r, hh) is local row roff(j) = (j & 3) + 8 (j >> 2) (a constant) + 4 hh of the slice, the
@@ -369,7 +372,8 @@ bwd_dkdv_wide_kernel(const KParams p, const int n_kblocks) {
                 vb[ks + PRE] = *(const i32x4 *)(vt + rd(ks + PRE));
             }
             dp = mma32<BF16>(da[ks], vb[ks], dp);
-            s[ks] = __builtin_amdgcn_exp2f(s[ks] * c2);
+#pragma unroll
+            for (int j = ks * 16 / KS; j < (ks + 1) * 16 / KS; j++) s[j] = __builtin_amdgcn_exp2f(s[j] * c2);   // (one per MFMA at KS = 16)
             if (ks == KS - 2) load_tr(0, 0);
             if (ks == KS - 1) load_tr(1, 1);
         }
@@ -435,13 +439,13 @@ bwd_dkdv_wide_kernel(const KParams p, const int n_kblocks) {
     }
 }
 
-template <bool BF16>
+template <bool BF16, int DV>
 static hipError_t launch_wide(const KParams &p, hipStream_t stream) {
     using Cfg = BwdWideCfg;
     const int n_kblocks = (p.seqlen_k + Cfg::KB - 1) / Cfg::KB;
     const long long blocks = (long long)n_kblocks * p.b * p.h_k;
     if (blocks <= 0) return hipSuccess;
-    auto kern = bwd_dkdv_wide_kernel<BF16>;
+    auto kern = bwd_dkdv_wide_kernel<BF16, DV>;
     static std::atomic<uint64_t> lds_set{0};
     if (hipError_t e = set_dyn_lds_once((const void *)kern, Cfg::LDS_BYTES, lds_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p, n_kblocks);
@@ -451,7 +455,10 @@ static hipError_t launch_wide(const KParams &p, hipStream_t stream) {
 // 128 < d <= 256, no dropout, no head split; the caller has checked that the Q / dO extents fit a
 // 32-bit buffer offset.
 hipError_t run_bwd_dkdv_wide(const KParams &p, hipStream_t stream) {
-    return p.is_bf16 ? launch_wide<true>(p, stream) : launch_wide<false>(p, stream);
+    // head dims up to 160 / 192 stop their products at that column
+    if (p.d <= 160) return p.is_bf16 ? launch_wide<true, 160>(p, stream) : launch_wide<false, 160>(p, stream);
+    if (p.d <= 192) return p.is_bf16 ? launch_wide<true, 192>(p, stream) : launch_wide<false, 192>(p, stream);
+    return p.is_bf16 ? launch_wide<true, 256>(p, stream) : launch_wide<false, 256>(p, stream);
 }
 
 }  // namespace vfa
