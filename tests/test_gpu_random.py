@@ -15,7 +15,7 @@ def _cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n):
-        d = int(rng.choice([32, 64, 64, 96, 128, 128, 128, 160, 256]))
+        d = int(rng.choice([32, 64, 64, 80, 96, 128, 128, 128, 160, 192, 256]))
         hk = int(rng.choice([1, 2, 3]))
         h = hk * int(rng.choice([1, 1, 2, 4]))
         sq = int(rng.choice(EDGE))
@@ -86,7 +86,7 @@ def _varlen_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n):
-        d = int(rng.choice([64, 128]))
+        d = int(rng.choice([64, 128, 128, 96, 176]))
         hk = int(rng.choice([1, 2]))
         h = hk * int(rng.choice([1, 2, 4]))
         nb = int(rng.integers(2, 5))
