@@ -383,8 +383,8 @@ def test_padded_head_dim_in_the_eight_wave_kernels(case):
     _check_grads(grads, ref, dt)
 
 
-# ---- head dims 65..96: the kernels stop their products at column 96 ----
-CUT96 = [
+# ---- head dims 65..96 and 129..192: the kernels stop their products at column 96 / 160 / 192 ----
+CUT = [
     # b, sq, sk, h, hk, d, causal, window
     (2, 777, 777, 4, 4, 96, True, (-1, -1)),
     (2, 777, 1300, 4, 2, 80, False, (-1, -1)),        # grouped heads, key tail
@@ -402,7 +402,7 @@ CUT96 = [
 ]
 
 
-@pytest.mark.parametrize("case", CUT96, ids=[str(c) for c in CUT96])
+@pytest.mark.parametrize("case", CUT, ids=[str(c) for c in CUT])
 def test_cut_off_head_dims_equal_the_zero_padded_call_bit_for_bit(case):
     """A head dim of 65..96 runs the d = 128 tiles with the MFMA loops cut off at column 96 (129..192:
     the d = 256 tiles cut off at 160 or 192).  What is skipped multiplies zero padding, so the same
