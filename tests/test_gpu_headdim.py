@@ -429,3 +429,28 @@ def test_cut_off_head_dims_equal_the_zero_padded_call_bit_for_bit(case):
     for a, a_p in ((dq, dq_p), (dk, dk_p), (dv, dv_p)):
         assert torch.isfinite(a.float()).all()
         assert torch.equal(a, a_p[..., :d]) and not a_p[..., d:].any()
+
+
+@pytest.mark.parametrize("d", [72, 96])
+@pytest.mark.parametrize("splits", [2, 5])
+def test_split_prefill_at_cut_off_head_dims_equals_the_zero_padded_call(d, splits):
+    """The split-KV variants of the prefill kernel (chunked prefill against a long cache in a small
+    batch) stop their products at column 96 too: same bits as the call padded to d = 128, and the
+    oracle's result."""
+    import cabi
+    import torch.nn.functional as F
+    from oracle import fa_oracle
+    from gpu_util import f32, ulp_tol
+    torch.manual_seed(d + splits)
+    b, sq, sk, h, hk = 1, 200, 3000, 4, 2
+    q = torch.randn(b, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(b, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    kw = dict(causal=True, softmax_scale=d ** -0.5, kvcache=True, num_splits=splits)
+    out, lse = cabi.fwd(q, k, v, **kw)
+    pad = lambda t: F.pad(t, (0, 128 - d))
+    out_p, lse_p = cabi.fwd(pad(q), pad(k), pad(v), **kw)
+    assert torch.equal(out, out_p[..., :d]) and torch.equal(lse, lse_p)
+    ro, rl = fa_oracle.attention_fwd(f32(q), f32(k), f32(v), dtype="bf16", causal=True)[:2]
+    assert np.abs(f32(out) - ro).max() <= 2 * ulp_tol("bf16", ro)
+    assert np.abs(lse.cpu().numpy() - rl).max() <= 2e-3

@@ -1017,10 +1017,10 @@ hipError_t run_fwd_prefill(const KParams &p, hipStream_t stream) {
 
 #elif defined(VFA_SPLIT_TU)
 // Split-KV variants (4 waves; contiguous or buffer-paged K/V), a translation unit of their own.
-template <int DP, bool BF16>
+template <int DP, bool BF16, int DV = DP>
 static hipError_t launch_prefill_split(const KParams &p, hipStream_t stream) {
-    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, 3, false, true>(p, stream)
-                             : launch_prefill_impl<DP, BF16, 4, 4, false, true>(p, stream);
+    return kv_fits_buffer(p) ? launch_prefill_impl<DP, BF16, 4, 3, false, true, false, DV>(p, stream)
+                             : launch_prefill_impl<DP, BF16, 4, 4, false, true, false, DV>(p, stream);
 }
 // Whether the split variants can load this K/V layout (else the caller takes the decode kernel).
 bool fwd_prefill_split_ok(const KParams &p) {
@@ -1030,6 +1030,7 @@ bool fwd_prefill_split_ok(const KParams &p) {
 hipError_t run_fwd_prefill_split(const KParams &p, hipStream_t stream) {
     const bool bf = p.is_bf16;
     if (p.d <= 64) return bf ? launch_prefill_split<64, true>(p, stream) : launch_prefill_split<64, false>(p, stream);
+    if (p.d <= 96) return bf ? launch_prefill_split<128, true, 96>(p, stream) : launch_prefill_split<128, false, 96>(p, stream);   // (see run_fwd_prefill_96)
     if (p.d <= 128) return bf ? launch_prefill_split<128, true>(p, stream) : launch_prefill_split<128, false>(p, stream);
     return bf ? launch_prefill_split<256, true>(p, stream) : launch_prefill_split<256, false>(p, stream);
 }
