@@ -59,6 +59,9 @@ CASES = [
     ((4, 4096, 4096, 16, 16, 256, True), (WIDE, WIDE, B4)),  # d = 256: one wave per SIMD; hand-pipelined forward, dK/dV with all 256 columns in one workgroup
     ((1, 300, 520, 8, 2, 160, False), (WIDE, WIDE, B4)),
     ((4, 4096, 4096, 32, 8, 128, True), (P8, B8, P8)),       # grouped heads: 256-key blocks counted per KV head
+    ((8, 4096, 4096, 32, 32, 96, True), (B8, B8, P8)),       # head dims 65..96 (products cut off at column 96): the block forward from seqlen 4096,
+    ((8, 4096, 4096, 32, 32, 96, False), (B8, B8, P8)),      #   and no 64-key dK/dV kernel (it has no such cut)
+    ((16, 2048, 2048, 32, 32, 80, True), (P8, B8, P8)),
 ]
 
 

@@ -51,8 +51,12 @@ inline int fwd_geometry(const KParams &p, const int cus) {
     const long long blocks = row_blocks_256(p);
     const bool masked = p.is_causal || p.is_local;
     // (without a mask the walk is ahead of the block kernel from one block per CU: b1 h8 s8192 0.262 -> 0.253 ms)
+    // (head dims up to 96, whose kernels stop their products at column 96: from seqlen 4096 the block
+    //  kernels are 2-3 % ahead -- b8 s4096 h32 d96 causal 1.044 -> 1.021 ms, full 1.785 -> 1.733, b4
+    //  s8192 1.823 -> 1.785; at 2048 the walk is level (full) or 3.5 % ahead (causal), at 1024 9 % ahead)
+    const bool walk_pays = !(p.d <= 96 && p.seqlen_q >= 4096);
     if (g_tuning[3] == 2 ? fwd_prefill_persist_ok(p)
-                         : (g_tuning[3] != 1 && fwd_prefill_persist_ok(p) && blocks >= (masked ? 2LL : 1LL) * cus))
+                         : (g_tuning[3] != 1 && walk_pays && fwd_prefill_persist_ok(p) && blocks >= (masked ? 2LL : 1LL) * cus))
         return VFA_GEO_PERSIST8;
     if (g_tuning[6]) return g_tuning[6] == 1 ? VFA_GEO_BLOCK8 : VFA_GEO_BLOCK4;   // development switch 6
     if (blocks < cus || (masked && blocks < 2LL * cus)) return VFA_GEO_BLOCK4;
