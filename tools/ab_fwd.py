@@ -17,7 +17,8 @@ SHAPES = [(8, 4096, 32, 32, 128, True), (8, 4096, 32, 32, 128, False), (4, 8192,
           (16, 2048, 64, 8, 128, False), (16, 2048, 64, 8, 128, True),   # 12, 13: the shape of the programming guide's forward example
           (8, 4096, 32, 32, 96, True), (8, 4096, 32, 32, 96, False), (32, 512, 32, 32, 96, True), (8, 4096, 32, 32, 80, True),   # 14-17
           (4, 4096, 16, 16, 192, True), (4, 4096, 16, 16, 192, False), (4, 4096, 16, 16, 160, True), (4, 4096, 16, 16, 160, False),   # 18-21
-          (16, 2048, 32, 32, 96, True), (32, 1024, 32, 32, 96, True), (16, 2048, 32, 32, 96, False), (4, 8192, 32, 32, 96, True)]   # 22-25
+          (16, 2048, 32, 32, 96, True), (32, 1024, 32, 32, 96, True), (16, 2048, 32, 32, 96, False), (4, 8192, 32, 32, 96, True),   # 22-25
+          (1, 16384, 32, 32, 128, True), (2, 8192, 32, 32, 128, False), (1, 16384, 32, 32, 128, False), (16, 2048, 32, 32, 128, True)]   # 26-29
 
 
 def main():
