@@ -69,7 +69,8 @@ def _headers():
         os.path.join(INCLUDE, "vfa.h")]
 
 
-def _build_lib(lib, sources, objdir, defines, force):
+def _compile_jobs(sources, objdir, defines, force):
+    """hipcc command lines of the objects of one library that are out of date."""
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
     jobs = []
@@ -78,16 +79,33 @@ def _build_lib(lib, sources, objdir, defines, force):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + hdrs + [os.path.join(CSRC, e) for e in EXTRA_DEPS.get(src, [])]):
             jobs.append([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) + ["-c", s, "-o", o])
-    if jobs:
-        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-            for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
-                if r.returncode != 0:
-                    sys.stderr.write(r.stdout + r.stderr)
-                    raise RuntimeError("hipcc failed: " + " ".join(r.args))
+    return jobs
+
+
+def _run_jobs(jobs):
+    if not jobs:
+        return
+    # the translation units that take longest first (they bound the wall time of a cold build)
+    slow = ("fwd_prefill_wide", "bwd.hip", "bwd_d96", "fwd_prefill.hip", "fwd_prefill_d96", "fwd_prefill_pack", "bwd_dq_ilp", "bwd_drop")
+    jobs = sorted(jobs, key=lambda c: next((i for i, k in enumerate(slow) if k in c[-3]), len(slow)))
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError("hipcc failed: " + " ".join(r.args))
+
+
+def _link(lib, sources, objdir, rebuilt, force):
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in sources]
-    if force or jobs or _newer(lib, objs):
+    if force or rebuilt or _newer(lib, objs):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib
+
+
+def _build_lib(lib, sources, objdir, defines, force):
+    jobs = _compile_jobs(sources, objdir, defines, force)
+    _run_jobs(jobs)
+    return _link(lib, sources, objdir, bool(jobs), force)
 
 
 def build_hip(force=False):
@@ -169,9 +187,14 @@ def build_torch_ext(force=False):
 
 
 def build_all(force=False, torch_ext=True):
-    lib = build_hip(force)
+    # the objects of both libraries in one pool of compiler jobs, then the two links
+    dev_obj = os.path.join(OBJ, "dev")
+    j1 = _compile_jobs(HIP_SOURCES, OBJ, [], force)
+    j2 = _compile_jobs(DEV_SOURCES, dev_obj, ["-DVFA_DEV"], force)
+    _run_jobs(j1 + j2)
+    lib = _link(LIB, HIP_SOURCES, OBJ, bool(j1), force)
     ext = build_torch_ext(force) if torch_ext else None
-    build_dev(force)
+    _link(DEV_LIB, DEV_SOURCES, dev_obj, bool(j2), force)
     return lib, ext
 
 
