@@ -189,7 +189,7 @@ def test_varlen_paged_vs_oracle():
 @pytest.mark.parametrize("d,page,sq", [(128, 16, 300), (128, 64, 700), (128, 256, 4200), (128, 32, 4200),
                                        (64, 32, 500), (64, 16, 500), (256, 16, 260), (128, 48, 300),
                                        (192, 16, 300), (96, 32, 300), (40, 16, 200), (256, 64, 700),
-                                       (64, 128, 700), (224, 128, 4200)])
+                                       (64, 128, 700), (224, 128, 4200), (160, 64, 700), (144, 16, 1300)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("staged", [False, True])
 def test_varlen_paged_prefill_equals_contiguous(d, page, sq, causal, staged):

@@ -23,7 +23,7 @@ for it in range(n):
     dtn = str(rng.choice(["fp16", "bf16"]))
     dt = torch.float16 if dtn == "fp16" else torch.bfloat16
     b = int(rng.integers(1, 5))
-    d = int(rng.choice([64, 128, 128, 128, 96, 256]))
+    d = int(rng.choice([64, 128, 128, 128, 96, 256, 160, 192]))
     hk = int(rng.choice([1, 2, 4]))
     h = hk * int(rng.choice([1, 2, 4, 8]))
     kl = [int(rng.choice(LENS)) for _ in range(b)]
