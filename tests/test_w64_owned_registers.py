@@ -18,7 +18,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 @pytest.mark.parametrize("src,symbol,n_kernels", [("fwd_prefill_w64.hip", "_ZN3vfa22fwd_prefill_w64_kernel", 2),
-                                                  ("fwd_prefill_wide.hip", "_ZN3vfa23fwd_prefill_wide_kernel", 4)])
+                                                  ("fwd_prefill_wide.hip", "_ZN3vfa23fwd_prefill_wide_kernel", 6),
+                                                  ("fwd_prefill_wide_paged.hip", "_ZN3vfa23fwd_prefill_wide_kernel", 6)])
 def test_compiler_never_touches_the_owned_accumulator_registers(src, symbol, n_kernels):
     tmp = tempfile.mkdtemp()
     try:

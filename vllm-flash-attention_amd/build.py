@@ -26,7 +26,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libvfa_hip.so")
 HIP_SOURCES = ["api.hip", "fwd_prefill.hip", "fwd_splitkv.hip", "bwd.hip", "fwd_prefill_drop.hip",
                "bwd_drop.hip", "fwd_prefill_split.hip", "bwd_dkdv_w64.hip", "fwd_prefill_persist.hip", "bwd_dq_persist.hip",
-               "bwd_dkdv_wide.hip", "fwd_prefill_wide.hip", "bwd_dq_ilp.hip", "fwd_prefill_d64.hip", "fwd_prefill_pack.hip", "fwd_prefill_d96.hip", "bwd_d96.hip"]
+               "bwd_dkdv_wide.hip", "fwd_prefill_wide.hip", "bwd_dq_ilp.hip", "fwd_prefill_d64.hip", "fwd_prefill_pack.hip", "fwd_prefill_d96.hip", "bwd_d96.hip", "fwd_prefill_wide_paged.hip"]
 # The development library (libvfa_hip_dev.so, -DVFA_DEV) adds the kernels no shipped dispatch takes
 # and the kernel-variant switches (vfa_debug_set_tuning) that select them; the A/B tools and the
 # tests that check a shipped kernel against its alternative load it.  The product never does.
@@ -37,6 +37,7 @@ DEV_LIB = os.path.join(HERE, "libvfa_hip_dev.so")
 EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "bwd_dkdv_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "fwd_prefill_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "fwd_prefill_wide_paged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "fwd_prefill_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # The persistent dQ kernel under LLVM's ILP-first scheduler: the default one puts every LDS
                # read directly in front of its MFMA (read, wait, MFMA, read, wait, ...); this one issues
@@ -51,7 +52,7 @@ EXTRA_FLAGS = {"bwd_dkdv_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # longer sequences +4 %)
                "fwd_prefill_d64.hip": ["-fno-slp-vectorize"]}
 # the dropout translation units are one-line includes of the kernel sources
-EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"], "bwd_d96.hip": ["bwd.hip"], "bwd_dq_ilp.hip": ["bwd.hip"], "fwd_prefill_d64.hip": ["fwd_prefill.hip"], "fwd_prefill_d96.hip": ["fwd_prefill.hip"], "fwd_prefill_pack.hip": ["fwd_prefill.hip"],
+EXTRA_DEPS = {"fwd_prefill_drop.hip": ["fwd_prefill.hip"], "bwd_drop.hip": ["bwd.hip"], "bwd_d96.hip": ["bwd.hip"], "fwd_prefill_wide_paged.hip": ["fwd_prefill_wide.hip"], "bwd_dq_ilp.hip": ["bwd.hip"], "fwd_prefill_d64.hip": ["fwd_prefill.hip"], "fwd_prefill_d96.hip": ["fwd_prefill.hip"], "fwd_prefill_pack.hip": ["fwd_prefill.hip"],
               "fwd_prefill_split.hip": ["fwd_prefill.hip"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-I", INCLUDE, "-I", CSRC]

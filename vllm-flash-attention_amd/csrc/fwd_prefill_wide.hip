@@ -569,6 +569,34 @@ fwd_prefill_wide_kernel(const KParams p, const int n_mblocks) {
     }
 }
 
+// The launcher of one K/V layout (template parameter PAGED); the paged instantiations are built as a
+// translation unit of their own (fwd_prefill_wide_paged.hip), which halves the build's longest job.
+template <bool PAGED>
+static hipError_t launch_wide_fwd(const KParams &p, hipStream_t stream) {
+    const int n_mblocks = (p.seqlen_q + fw256::BM - 1) / fw256::BM;
+    const long long blocks = (long long)n_mblocks * p.b * p.h;
+    if (blocks <= 0) return hipSuccess;
+    static std::atomic<uint64_t> lds_set[6];
+    auto launch = [&](auto kern, std::atomic<uint64_t> &flag) -> hipError_t {
+        if (hipError_t e = set_dyn_lds_once((const void *)kern, fw256::LDS_BYTES, flag); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), fw256::LDS_BYTES, stream, p, n_mblocks);
+        return hipGetLastError();
+    };
+    // head dims up to 160 / 192 stop their products at that column (b4 s4096 h16 d192 causal 0.557 -> 0.496 ms, d160 0.544 -> 0.455)
+    auto pick = [&](auto DVC, const int at) -> hipError_t {
+        constexpr int DV = decltype(DVC)::value;
+        return p.is_bf16 ? launch(fwd_prefill_wide_kernel<true, PAGED, DV>, lds_set[at]) : launch(fwd_prefill_wide_kernel<false, PAGED, DV>, lds_set[at + 1]);
+    };
+    if (p.d <= 160) return pick(std::integral_constant<int, 160>{}, 0);
+    if (p.d <= 192) return pick(std::integral_constant<int, 192>{}, 2);
+    return pick(std::integral_constant<int, 256>{}, 4);
+}
+
+#ifdef VFA_WIDE_PAGED_TU
+hipError_t run_fwd_prefill_wide_paged(const KParams &p, hipStream_t stream) { return launch_wide_fwd<true>(p, stream); }
+#else
+hipError_t run_fwd_prefill_wide_paged(const KParams &p, hipStream_t stream);   // fwd_prefill_wide_paged.hip
+
 // Whether this kernel takes the call: head dims 129..256, K/V contiguous per (batch, head) within a
 // 32-bit buffer offset, no ALiBi (the caller checks dropout and split).
 bool fwd_prefill_wide_ok(const KParams &p) {
@@ -582,25 +610,8 @@ bool fwd_prefill_wide_ok(const KParams &p) {
 }
 
 hipError_t run_fwd_prefill_wide(const KParams &p, hipStream_t stream) {
-    const int n_mblocks = (p.seqlen_q + fw256::BM - 1) / fw256::BM;
-    const long long blocks = (long long)n_mblocks * p.b * p.h;
-    if (blocks <= 0) return hipSuccess;
-    static std::atomic<uint64_t> lds_set[12];
-    auto launch = [&](auto kern, std::atomic<uint64_t> &flag) -> hipError_t {
-        if (hipError_t e = set_dyn_lds_once((const void *)kern, fw256::LDS_BYTES, flag); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), fw256::LDS_BYTES, stream, p, n_mblocks);
-        return hipGetLastError();
-    };
-    // head dims up to 160 / 192 stop their products at that column (b4 s4096 h16 d192 causal 0.560 ms, d160 0.606 before)
-    auto pick = [&](auto DVC, const int at) -> hipError_t {
-        constexpr int DV = decltype(DVC)::value;
-        if (p.block_table)
-            return p.is_bf16 ? launch(fwd_prefill_wide_kernel<true, true, DV>, lds_set[at]) : launch(fwd_prefill_wide_kernel<false, true, DV>, lds_set[at + 1]);
-        return p.is_bf16 ? launch(fwd_prefill_wide_kernel<true, false, DV>, lds_set[at + 2]) : launch(fwd_prefill_wide_kernel<false, false, DV>, lds_set[at + 3]);
-    };
-    if (p.d <= 160) return pick(std::integral_constant<int, 160>{}, 0);
-    if (p.d <= 192) return pick(std::integral_constant<int, 192>{}, 4);
-    return pick(std::integral_constant<int, 256>{}, 8);
+    return p.block_table ? run_fwd_prefill_wide_paged(p, stream) : launch_wide_fwd<false>(p, stream);
 }
+#endif
 
 }  // namespace vfa
